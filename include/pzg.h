@@ -1,0 +1,140 @@
+/*
+ * pzg.h -- C ABI of the MI355X-native batched zlib/DEFLATE decompressor.
+ *
+ * This is the drop-in boundary for the one hot path of GaloisInc/pure-zlib:
+ *
+ *     Codec.Compression.Zlib.decompress :: L.ByteString -> Either DecompressionError L.ByteString
+ *         (reference: src/Codec/Compression/Zlib.hs:32-51)
+ *
+ * The reference is pure Haskell with no FFI of its own; these entry points are
+ * what a `foreign import ccall safe` in a replacement Codec.Compression.Zlib
+ * module binds (the binding a maintainer would add is shown in INTEGRATION.md).
+ * Plain pointers and sizes only; no C++/torch/HIP types cross the boundary.
+ *
+ * There is NO CPU backend: every entry point that computes runs hand-written
+ * HIP kernels on a gfx950 device and fails loudly (negative return code) when no
+ * device is usable.
+ *
+ * Threading: a pzg_ctx serialises its own calls internally (one HIP stream per
+ * context); distinct contexts may be used from distinct threads concurrently.
+ * Ownership: the caller allocates and owns every buffer; the library retains no
+ * caller pointer past return (except with PZG_ASYNC, until pzg_sync()).
+ * No exception crosses the boundary.
+ */
+#ifndef PZG_H
+#define PZG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PZG_VERSION_MAJOR 0
+#define PZG_VERSION_MINOR 1
+
+/* ---- call-level return codes (the int every function returns) ---------------- */
+#define PZG_RC_OK            0
+#define PZG_RC_BAD_ARG      (-1)
+#define PZG_RC_NO_DEVICE    (-2)  /* no gfx950 device / HIP runtime unusable: there is no CPU fallback */
+#define PZG_RC_HIP_ERROR    (-3)  /* a HIP call failed; pzg_last_error() has the text */
+#define PZG_RC_NO_MEMORY    (-4)
+
+/* ---- per-stream status codes --------------------------------------------------
+ * One per reference outcome.  `show` strings are those of
+ * src/Codec/Compression/Zlib/Monad.hs:95-102 plus the raise site quoted. */
+#define PZG_OK                    0  /* Right bytes                                              Zlib.hs:46-47  */
+#define PZG_E_TRUNCATED           1  /* DecompressionError "Ran out of data mid-decompression 2." Zlib.hs:38-39  */
+#define PZG_E_HDR_FCHECK          2  /* HeaderError "Header checksum failed"                      Zlib.hs:62-63  */
+#define PZG_E_HDR_METHOD          3  /* HeaderError "Bad compression method: <d0>"                Zlib.hs:64-65  */
+#define PZG_E_HDR_WINDOW          4  /* HeaderError "Window size too big: <d0>"                   Zlib.hs:66-67  */
+#define PZG_E_FMT_LEN_NLEN        5  /* FormatError "Len/nlen mismatch in uncompressed block."    Deflate.hs:75-76 */
+#define PZG_E_FMT_BTYPE           6  /* FormatError "Unacceptable BTYPE: 3"                       Deflate.hs:102-104 */
+#define PZG_E_HUFF_BUILD          7  /* HuffmanTreeError <insert message>; d0 = tree id, d1 = bit offset of the block header
+                                        (pzg_error_message re-derives the exact text)             HuffmanTree.hs:55-63 */
+#define PZG_E_HUFF_EMPTY_TREE     8  /* HuffmanTreeError "Tried to advance empty tree!"           HuffmanTree.hs:76 */
+#define PZG_E_HUFF_EMPTY_BRANCH   9  /* HuffmanTreeError "Advanced to empty tree!"                HuffmanTree.hs:80 */
+#define PZG_E_CHECKSUM           10  /* ChecksumError "checksum mismatch: <hex d0> != <hex d1>"   Deflate.hs:56-63 */
+#define PZG_E_BAD_DISTANCE       11  /* reference THROWS (OutputWindow.hs:87 slice bounds); d0 = distance, d1 = bytes produced */
+#define PZG_E_BAD_LITLEN_SYMBOL  12  /* reference THROWS (Deflate.hs:160-166 array index); d0 = symbol 286/287 */
+#define PZG_E_BAD_DIST_SYMBOL    13  /* reference THROWS (Deflate.hs:199-205 array index); d0 = symbol >= 30 */
+#define PZG_E_OUT_TOO_SMALL      14  /* not a reference outcome: out_len[i] holds the size needed */
+#define PZG_E_DATA_REMAINING     15  /* DecompressionError "Finished with data remaining." -- produced by the host
+                                        mirror from in_used[] and the caller's chunking (Zlib.hs:48-49), never by the kernel */
+
+/* tree ids in detail[2*i] of PZG_E_HUFF_BUILD */
+#define PZG_TREE_CODELEN 0
+#define PZG_TREE_LITLEN  1
+#define PZG_TREE_DIST    2
+
+/* ---- flags ------------------------------------------------------------------- */
+#define PZG_DEVICE_PTRS  1u  /* every pointer argument is device memory on the context's device */
+#define PZG_ASYNC        2u  /* enqueue only (requires PZG_DEVICE_PTRS); caller calls pzg_sync() */
+
+typedef struct pzg_ctx pzg_ctx;
+
+/* Create a context on HIP device `device` (0-based).  One HIP stream + grow-only device
+ * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device. */
+int  pzg_init(int device, pzg_ctx **out);
+void pzg_shutdown(pzg_ctx *ctx);
+
+/* Make the context launch on an existing HIP stream (e.g. a framework's current stream)
+ * instead of its own.  `hip_stream` is a hipStream_t passed as void*; NULL restores the own stream. */
+int  pzg_set_stream(pzg_ctx *ctx, void *hip_stream);
+int  pzg_sync(pzg_ctx *ctx);
+
+/*
+ * decompressMany: decode n independent zlib (RFC 1950) streams, one wavefront per stream.
+ * Replaces n calls of Codec.Compression.Zlib.decompress (Zlib.hs:32-51) on single-chunk inputs.
+ *
+ *   in_base, in_off[n], in_len[n]    stream i is in_base[in_off[i] .. in_off[i]+in_len[i])
+ *   out_base, out_off[n], out_cap[n] stream i may write out_base[out_off[i] .. out_off[i]+out_cap[i])
+ *   out_len[n]             bytes the stream decodes to (may exceed the capacity: PZG_E_OUT_TOO_SMALL)
+ *   status[n]              PZG_OK or PZG_E_*
+ *   detail[2n]             two detail words per stream (see the status table); may be NULL
+ *   in_used[n]             input bytes consumed incl. the Adler trailer; may be NULL
+ *   adler[n]               Adler-32 computed over the decoded bytes; may be NULL
+ *
+ * Extents may be laid out with gaps (aligned arenas) and in any order; they must not overlap on the
+ * output side.  A 16-byte aligned out_base+out_off[i] takes the wide (16 B/lane) store path.
+ *
+ * Without PZG_DEVICE_PTRS all pointers are host memory and the call stages through the
+ * context's device arenas (H2D, kernel, D2H) and returns when results are in host memory.
+ * Return value: PZG_RC_* for the call as a whole; per-stream results are in status[].
+ */
+int pzg_decompress_many(pzg_ctx *ctx,
+                        const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len,
+                        uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap,
+                        uint64_t *out_len, int32_t *status, uint32_t *detail,
+                        uint64_t *in_used, uint32_t *adler,
+                        uint32_t n, uint32_t flags);
+
+/* decompress: the single-stream form (n = 1, host pointers). */
+int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len,
+                   uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                   int32_t *status, uint32_t detail[2], uint64_t *in_used);
+
+/* Adler-32 of one buffer (Codec.Compression.Zlib.Adler32, Adler32.hs:17-57) as a device-wide
+ * reduction.  `init` is a finalized Adler value (1 for a fresh checksum). */
+int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init,
+                uint32_t *out, uint32_t flags);
+
+/* Exact `show` text of the DecompressionError the reference returns for (status, detail) on
+ * this stream (host memory; needed only for PZG_E_HUFF_BUILD, whose message depends on the
+ * trie insertion order).  Writes a NUL-terminated string; returns its length. */
+int pzg_error_message(const uint8_t *in, uint64_t in_len, int32_t status,
+                      const uint32_t detail[2], char *buf, size_t buf_len);
+
+/* Kernel time of the last launch on this context in milliseconds (HIP events on the launch
+ * stream), or a negative value if none was recorded. */
+double pzg_last_kernel_ms(pzg_ctx *ctx);
+
+const char *pzg_strerror(int rc);
+const char *pzg_last_error(pzg_ctx *ctx);
+uint32_t    pzg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PZG_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libpzg.so (include/pzg.h).
+
+The library is the only compute path of this package: if it is missing, or HIP has no usable
+device, the calls raise.  There is no CPU fallback anywhere in pure_zlib_amd.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpzg.so")
+
+RC_OK, RC_BAD_ARG, RC_NO_DEVICE, RC_HIP_ERROR, RC_NO_MEMORY = 0, -1, -2, -3, -4
+
+OK = 0
+E_TRUNCATED = 1
+E_HDR_FCHECK = 2
+E_HDR_METHOD = 3
+E_HDR_WINDOW = 4
+E_FMT_LEN_NLEN = 5
+E_FMT_BTYPE = 6
+E_HUFF_BUILD = 7
+E_HUFF_EMPTY_TREE = 8
+E_HUFF_EMPTY_BRANCH = 9
+E_CHECKSUM = 10
+E_BAD_DISTANCE = 11
+E_BAD_LITLEN_SYMBOL = 12
+E_BAD_DIST_SYMBOL = 13
+E_OUT_TOO_SMALL = 14
+E_DATA_REMAINING = 15
+
+DEVICE_PTRS = 1
+ASYNC = 2
+
+# every symbol include/pzg.h declares
+SYMBOLS = [
+    "pzg_init", "pzg_shutdown", "pzg_set_stream", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
+    "pzg_adler32", "pzg_error_message", "pzg_last_kernel_ms", "pzg_strerror", "pzg_last_error", "pzg_version",
+]
+
+
+class PzgError(RuntimeError):
+    """Call-level failure of the library (not a per-stream DecompressionError)."""
+
+
+_lib = None
+
+
+def lib():
+    """Load libpzg.so.  Raises if the HIP extension has not been built: the product has no other path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PzgError(
+            f"{LIB_PATH} is missing: build it with `make -C pure_zlib_amd/csrc` "
+            "(or __graft_entry__.build()).  pure_zlib_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64p, i32p, u32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.pzg_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.pzg_init.restype = C.c_int
+    L.pzg_shutdown.argtypes = [C.c_void_p]
+    L.pzg_shutdown.restype = None
+    L.pzg_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.pzg_set_stream.restype = C.c_int
+    L.pzg_sync.argtypes = [C.c_void_p]
+    L.pzg_sync.restype = C.c_int
+    L.pzg_decompress_many.argtypes = [C.c_void_p, vp, u64p, u64p, vp, u64p, u64p, u64p, i32p, u32p, u64p, u32p,
+                                      C.c_uint32, C.c_uint32]
+    L.pzg_decompress_many.restype = C.c_int
+    L.pzg_decompress.argtypes = [C.c_void_p, vp, C.c_uint64, vp, C.c_uint64, u64p, i32p, u32p, u64p]
+    L.pzg_decompress.restype = C.c_int
+    L.pzg_adler32.argtypes = [C.c_void_p, vp, C.c_uint64, C.c_uint32, u32p, C.c_uint32]
+    L.pzg_adler32.restype = C.c_int
+    L.pzg_error_message.argtypes = [vp, C.c_uint64, C.c_int32, u32p, C.c_char_p, C.c_size_t]
+    L.pzg_error_message.restype = C.c_int
+    L.pzg_last_kernel_ms.argtypes = [C.c_void_p]
+    L.pzg_last_kernel_ms.restype = C.c_double
+    L.pzg_strerror.argtypes = [C.c_int]
+    L.pzg_strerror.restype = C.c_char_p
+    L.pzg_last_error.argtypes = [C.c_void_p]
+    L.pzg_last_error.restype = C.c_char_p
+    L.pzg_version.argtypes = []
+    L.pzg_version.restype = C.c_uint32
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None):
+    if rc != RC_OK:
+        L = lib()
+        msg = L.pzg_strerror(rc).decode()
+        if ctx is not None and rc == RC_HIP_ERROR:
+            msg += ": " + L.pzg_last_error(ctx).decode()
+        raise PzgError(f"libpzg call failed ({rc}): {msg}")

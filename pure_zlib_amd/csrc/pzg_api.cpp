@@ -1,0 +1,309 @@
+// pzg_api.cpp -- the C ABI of include/pzg.h: a thin HIP launcher around the kernels.
+//
+// No CPU decode path exists in this library.  Every compute entry point launches the gfx950
+// kernels of pzg_kernels.hip; when HIP has no usable device the calls fail with PZG_RC_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "../../include/pzg.h"
+#include "pzg_launch.h"
+
+namespace {
+
+struct Arena {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+constexpr uint32_t ADLER_MAX_WAVES = 8192;  // 256 CUs x 32 waves
+
+}  // namespace
+
+struct pzg_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::mutex mu;
+    Arena a_in, a_out, a_meta, a_adler;
+    void *h_stage = nullptr;  // pinned host staging for the host-pointer path
+    size_t h_stage_cap = 0;
+    std::string last_error;
+};
+
+namespace {
+
+int hip_fail(pzg_ctx *ctx, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    if (ctx) ctx->last_error = buf;
+    return PZG_RC_HIP_ERROR;
+}
+
+#define HIP_TRY(ctx, call)                                  \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+int arena_reserve(pzg_ctx *ctx, Arena &a, size_t bytes)
+{
+    bytes = (bytes + 255u) & ~(size_t)255u;
+    if (bytes == 0) bytes = 256;
+    if (a.cap >= bytes) return PZG_RC_OK;
+    if (a.p) HIP_TRY(ctx, hipFree(a.p));
+    a.p = nullptr;
+    a.cap = 0;
+    hipError_t e = hipMalloc(&a.p, bytes);
+    if (e != hipSuccess) {
+        hip_fail(ctx, e, "hipMalloc");
+        return PZG_RC_NO_MEMORY;
+    }
+    a.cap = bytes;
+    return PZG_RC_OK;
+}
+
+int launch_timed(pzg_ctx *ctx, const pzg::InflateArgs &args)
+{
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(ctx, pzg::launch_inflate(args, 15, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return PZG_RC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pzg_init(int device, pzg_ctx **out)
+{
+    if (!out) return PZG_RC_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return PZG_RC_NO_DEVICE;
+    if (device < 0 || device >= ndev) return PZG_RC_BAD_ARG;
+    pzg_ctx *ctx = new (std::nothrow) pzg_ctx();
+    if (!ctx) return PZG_RC_NO_MEMORY;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return PZG_RC_NO_DEVICE;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return PZG_RC_OK;
+}
+
+void pzg_shutdown(pzg_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (Arena *a : {&ctx->a_in, &ctx->a_out, &ctx->a_meta, &ctx->a_adler})
+        if (a->p) (void)hipFree(a->p);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pzg_set_stream(pzg_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return PZG_RC_BAD_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PZG_RC_OK;
+}
+
+int pzg_sync(pzg_ctx *ctx)
+{
+    if (!ctx) return PZG_RC_BAD_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PZG_RC_OK;
+}
+
+int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len,
+                        uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
+                        int32_t *status, uint32_t *detail, uint64_t *in_used, uint32_t *adler, uint32_t n,
+                        uint32_t flags)
+{
+    if (!ctx) return PZG_RC_BAD_ARG;
+    if (n == 0) return PZG_RC_OK;
+    if (!in_base || !in_off || !in_len || !out_off || !out_cap || !out_len || !status) return PZG_RC_BAD_ARG;
+    if ((flags & PZG_ASYNC) && !(flags & PZG_DEVICE_PTRS)) return PZG_RC_BAD_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    if (flags & PZG_DEVICE_PTRS) {
+        if (!out_base) return PZG_RC_BAD_ARG;
+        pzg::InflateArgs a{in_base, in_off, in_len, out_base, out_off, out_cap, out_len,
+                           status,  detail, in_used, adler,   nullptr, n};
+        int rc = launch_timed(ctx, a);
+        if (rc != PZG_RC_OK) return rc;
+        if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return PZG_RC_OK;
+    }
+
+    // host-pointer path: stage the covering byte ranges through the context's arenas
+    uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (in_off[i] < in_lo) in_lo = in_off[i];
+        if (in_off[i] + in_len[i] > in_hi) in_hi = in_off[i] + in_len[i];
+        if (out_off[i] < out_lo) out_lo = out_off[i];
+        if (out_off[i] + out_cap[i] > out_hi) out_hi = out_off[i] + out_cap[i];
+    }
+    const uint64_t in_bytes = in_hi - in_lo, out_bytes = out_hi - out_lo;
+    if (out_bytes && !out_base) return PZG_RC_BAD_ARG;
+    // keep every stream's address alignment (mod 16) on the device what it is on the host
+    const uint32_t in_skew = (uint32_t)(((uintptr_t)in_base + in_lo) & 15u);
+    const uint32_t out_skew = (uint32_t)(((uintptr_t)out_base + out_lo) & 15u);
+    int rc;
+    if ((rc = arena_reserve(ctx, ctx->a_in, in_bytes + 64)) != PZG_RC_OK) return rc;
+    if ((rc = arena_reserve(ctx, ctx->a_out, out_bytes + 64)) != PZG_RC_OK) return rc;
+    // meta layout: in_off | in_len | out_off | out_cap | out_len | in_used  (u64[n] each)
+    //              | status | adler (32-bit [n] each) | detail u32[2n]
+    const size_t N = n;
+    const size_t m_in_off = 0, m_in_len = 8 * N, m_out_off = 16 * N, m_out_cap = 24 * N, m_out_len = 32 * N,
+                 m_in_used = 40 * N, m_status = 48 * N, m_adler = 52 * N, m_detail = 56 * N, m_total = 64 * N;
+    if ((rc = arena_reserve(ctx, ctx->a_meta, m_total)) != PZG_RC_OK) return rc;
+    uint8_t *d_in = (uint8_t *)ctx->a_in.p + in_skew;
+    uint8_t *d_out = (uint8_t *)ctx->a_out.p + out_skew;
+    uint8_t *d_meta = (uint8_t *)ctx->a_meta.p;
+    hipStream_t s = ctx->stream;
+    if (in_bytes) HIP_TRY(ctx, hipMemcpyAsync(d_in, in_base + in_lo, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_off, in_off, 8 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_len, in_len, 8 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_off, out_off, 8 * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_cap, out_cap, 8 * N, hipMemcpyHostToDevice, s));
+    pzg::InflateArgs a{};
+    a.in_base = d_in - in_lo;  // offsets stay the caller's
+    a.out_base = d_out - out_lo;
+    a.in_off = (const uint64_t *)(d_meta + m_in_off);
+    a.in_len = (const uint64_t *)(d_meta + m_in_len);
+    a.out_off = (const uint64_t *)(d_meta + m_out_off);
+    a.out_cap = (const uint64_t *)(d_meta + m_out_cap);
+    a.out_len = (uint64_t *)(d_meta + m_out_len);
+    a.in_used = (uint64_t *)(d_meta + m_in_used);
+    a.status = (int32_t *)(d_meta + m_status);
+    a.adler = (uint32_t *)(d_meta + m_adler);
+    a.detail = (uint32_t *)(d_meta + m_detail);
+    a.order = nullptr;
+    a.n = n;
+    if ((rc = launch_timed(ctx, a)) != PZG_RC_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_len, a.out_len, 8 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(status, a.status, 4 * N, hipMemcpyDeviceToHost, s));
+    if (in_used) HIP_TRY(ctx, hipMemcpyAsync(in_used, a.in_used, 8 * N, hipMemcpyDeviceToHost, s));
+    if (adler) HIP_TRY(ctx, hipMemcpyAsync(adler, a.adler, 4 * N, hipMemcpyDeviceToHost, s));
+    if (detail) HIP_TRY(ctx, hipMemcpyAsync(detail, a.detail, 8 * N, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    // copy back only what each stream produced (capacities may be far larger than the outputs)
+    // One D2H transfer of the covering range into pinned staging, then per-stream copies into the
+    // caller's extents: bytes outside [out_off, out_off + min(out_len, out_cap)) are never touched.
+    if (out_bytes) {
+        if (ctx->h_stage_cap < out_bytes) {
+            if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
+            ctx->h_stage = nullptr;
+            ctx->h_stage_cap = 0;
+            hipError_t e = hipHostMalloc(&ctx->h_stage, out_bytes + 64, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                hip_fail(ctx, e, "hipHostMalloc");
+                return PZG_RC_NO_MEMORY;
+            }
+            ctx->h_stage_cap = out_bytes;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t nb = out_len[i] < out_cap[i] ? out_len[i] : out_cap[i];
+            if (nb) memcpy(out_base + out_off[i], (const uint8_t *)ctx->h_stage + (out_off[i] - out_lo), nb);
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return PZG_RC_OK;
+}
+
+int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
+                   uint64_t *out_len, int32_t *status, uint32_t detail[2], uint64_t *in_used)
+{
+    if (!out_len || !status) return PZG_RC_BAD_ARG;
+    static const uint8_t dummy_in = 0;
+    static uint8_t dummy_out = 0;
+    const uint64_t zero = 0;
+    return pzg_decompress_many(ctx, in ? in : &dummy_in, &zero, &in_len, out ? out : &dummy_out, &zero, &out_cap,
+                               out_len, status, detail, in_used, nullptr, 1, 0);
+}
+
+int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *out, uint32_t flags)
+{
+    if (!ctx || !out || (!buf && len)) return PZG_RC_BAD_ARG;
+    if ((flags & PZG_ASYNC) && !(flags & PZG_DEVICE_PTRS)) return PZG_RC_BAD_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = arena_reserve(ctx, ctx->a_adler, 12 * (size_t)(ADLER_MAX_WAVES + 4) + 16)) != PZG_RC_OK) return rc;
+    uint32_t *partials = (uint32_t *)ctx->a_adler.p;
+    uint32_t *d_res = partials + 3 * (size_t)(ADLER_MAX_WAVES + 4);
+    hipStream_t s = ctx->stream;
+    if (flags & PZG_DEVICE_PTRS) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+        HIP_TRY(ctx, pzg::launch_adler32(buf, len, init, partials, ADLER_MAX_WAVES, out, s));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+        ctx->timed = true;
+        if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(s));
+        return PZG_RC_OK;
+    }
+    const uint32_t skew = (uint32_t)((uintptr_t)buf & 15u);
+    if ((rc = arena_reserve(ctx, ctx->a_in, len + 64)) != PZG_RC_OK) return rc;
+    uint8_t *d_buf = (uint8_t *)ctx->a_in.p + skew;
+    if (len) HIP_TRY(ctx, hipMemcpyAsync(d_buf, buf, len, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
+    HIP_TRY(ctx, pzg::launch_adler32(d_buf, len, init, partials, ADLER_MAX_WAVES, d_res, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
+    ctx->timed = true;
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_res, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return PZG_RC_OK;
+}
+
+double pzg_last_kernel_ms(pzg_ctx *ctx)
+{
+    if (!ctx) return -1.0;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!ctx->timed) return -1.0;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+const char *pzg_strerror(int rc)
+{
+    switch (rc) {
+    case PZG_RC_OK: return "ok";
+    case PZG_RC_BAD_ARG: return "bad argument";
+    case PZG_RC_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case PZG_RC_HIP_ERROR: return "HIP runtime error";
+    case PZG_RC_NO_MEMORY: return "out of memory";
+    default: return "unknown return code";
+    }
+}
+
+const char *pzg_last_error(pzg_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+uint32_t pzg_version(void) { return (PZG_VERSION_MAJOR << 16) | PZG_VERSION_MINOR; }
+
+}  // extern "C"

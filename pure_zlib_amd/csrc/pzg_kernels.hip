@@ -1,0 +1,210 @@
+// pzg_kernels.hip -- gfx950 kernels + their launchers.
+//
+//   inflate_kernel<RING_BITS>   one workgroup = one wavefront = one zlib stream (inflate_core.h)
+//   adler32_partial_kernel      Adler32.hs as an HBM-bound streaming reduction (BASELINE config 2)
+//   adler32_combine_kernel      folds the per-wave partials in order
+//
+// Written for CDNA4 only: wave64, LDS ring per wave, no MFMA (there is no contraction on this path).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "inflate_core.h"
+#include "pzg_launch.h"
+
+namespace pzg {
+
+// ------------------------------------------------------------------------------------------------
+// inflate: grid = number of streams, block = 64 threads.  LDS per workgroup = sizeof(WaveLds) =
+// 38.7 KiB at RING_BITS = 15, so four stream-waves are resident per CU (one per SIMD).
+template <int RING_BITS>
+__global__ __launch_bounds__(64) void inflate_kernel(InflateArgs a)
+{
+    __shared__ WaveLds<RING_BITS> lds;
+    uint32_t i = blockIdx.x;
+    if (a.order) i = a.order[i];
+    Decoder<RING_BITS> dec(lds);
+    StreamResult r;
+    dec.run(a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i], &r);
+    if (threadIdx.x == 0) {
+        a.status[i] = r.status;
+        a.out_len[i] = r.out_len;
+        if (a.detail) {
+            a.detail[2 * (size_t)i] = r.detail0;
+            a.detail[2 * (size_t)i + 1] = r.detail1;
+        }
+        if (a.in_used) a.in_used[i] = r.in_used;
+        if (a.adler) a.adler[i] = r.adler;
+    }
+}
+
+hipError_t launch_inflate(const InflateArgs &a, int ring_bits, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    dim3 grid(a.n), block(64);
+    if (ring_bits == 15)
+        hipLaunchKernelGGL(inflate_kernel<15>, grid, block, 0, stream, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adler-32 (Adler32.hs:17-57) over one large buffer.
+//
+// The buffer is viewed as 16-byte vectors at aligned addresses; the bytes of the first and last
+// vector that fall outside [buf, buf+len) are masked to zero (zeros add nothing to either sum and
+// the position weights are taken from the END of the buffer, so leading padding is harmless).
+// Each wave owns a contiguous run of 64 KiB blocks (4096 vectors); within a block lane l reads
+// vector it*64 + l (one fully coalesced 1 KiB wave-load per iteration) and keeps three u32
+// partial sums.  For a zero-initialised run X followed by Y:
+//     SA = SA_x + SA_y          SB = SB_x + len_y * SA_x + SB_y          (mod 65521)
+// with SA = sum d, SB = sum (n - pos) d.
+constexpr uint32_t AD_BLOCK_VECS = 4096;  // 64 KiB per block: u32 lane sums cannot overflow
+constexpr uint32_t AD_UNROLL = 8;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void adler_acc(u32x4 v, uint32_t it, uint32_t &a, uint32_t &w, uint32_t &u)
+{
+    uint32_t s = sum4(v.x, sum4(v.y, sum4(v.z, sum4(v.w, 0u))));
+    uint32_t t = dot4(v.x, 0x0D0E0F10u, dot4(v.y, 0x090A0B0Cu, dot4(v.z, 0x05060708u, dot4(v.w, 0x01020304u, 0u))));
+    a += s;
+    w += t;
+    u += it * s;
+}
+
+__device__ __forceinline__ u32x4 mask_vec(u32x4 v, uint32_t lo, uint32_t hi)
+{
+    // keep bytes [lo, hi) of the 16
+    uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) {
+            uint32_t idx = 4 * k + b;
+            if (idx >= lo && idx < hi) m |= 0xffu << (8 * b);
+        }
+        x[k] &= m;
+    }
+    u32x4 r = {x[0], x[1], x[2], x[3]};
+    return r;
+}
+
+__global__ __launch_bounds__(256) void adler32_partial_kernel(const uint8_t *abase, uint64_t nvec, uint32_t head_pad,
+                                                             uint32_t tail_valid, uint64_t nblocks,
+                                                             uint32_t blocks_per_wave, uint32_t *partials)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t b0 = wave * blocks_per_wave;
+    uint64_t b1 = b0 + blocks_per_wave;
+    if (b1 > nblocks) b1 = nblocks;
+    uint32_t SA = 0, SB = 0;  // running sums of this wave's run, mod 65521
+    uint64_t run_bytes = 0;
+    const u32x4 *vbase = (const u32x4 *)abase;
+    for (uint64_t b = b0; b < b1; ++b) {
+        const uint64_t v0 = b * AD_BLOCK_VECS;
+        const uint32_t nv = (uint32_t)((nvec - v0) < AD_BLOCK_VECS ? (nvec - v0) : AD_BLOCK_VECS);
+        uint32_t a_l = 0, w_l = 0, u_l = 0;
+        const bool edge = (b == 0) || (v0 + nv == nvec) || nv < AD_BLOCK_VECS;
+        if (!edge) {
+            const u32x4 *p = vbase + v0 + lane;
+            for (uint32_t it = 0; it < AD_BLOCK_VECS / 64u; it += AD_UNROLL) {
+                u32x4 v[AD_UNROLL];
+#pragma unroll
+                for (uint32_t q = 0; q < AD_UNROLL; ++q) v[q] = __builtin_nontemporal_load(p + (size_t)(it + q) * 64u);
+#pragma unroll
+                for (uint32_t q = 0; q < AD_UNROLL; ++q) adler_acc(v[q], it + q, a_l, w_l, u_l);
+            }
+        } else {
+            for (uint32_t it = 0; it * 64u < nv; ++it) {
+                const uint32_t j = it * 64u + lane;
+                if (j < nv) {
+                    u32x4 v = vbase[v0 + j];
+                    const uint64_t gv = v0 + j;
+                    uint32_t lo = gv == 0 ? head_pad : 0u;
+                    uint32_t hi = gv == nvec - 1 ? tail_valid : 16u;
+                    if (lo != 0u || hi != 16u) v = mask_vec(v, lo, hi);
+                    adler_acc(v, it, a_l, w_l, u_l);
+                }
+            }
+        }
+        const uint32_t n = nv * 16u;  // block length in (padded) bytes
+        int64_t bl = ((int64_t)n - 16 * (int64_t)lane - 16) * (int64_t)a_l + (int64_t)w_l - 1024 * (int64_t)u_l;
+        uint32_t blk_b = wave_sum((uint32_t)((uint64_t)bl % ADLER_MOD));
+        uint32_t blk_a = wave_sum(a_l) % ADLER_MOD;
+        SB = (uint32_t)(((uint64_t)SB + (uint64_t)(n % ADLER_MOD) * SA + blk_b) % ADLER_MOD);
+        SA = (SA + blk_a) % ADLER_MOD;
+        run_bytes += n;
+    }
+    if (lane == 0) {
+        partials[3 * wave + 0] = SA;
+        partials[3 * wave + 1] = SB;
+        partials[3 * wave + 2] = (uint32_t)(run_bytes % ADLER_MOD);
+    }
+}
+
+// One wave folds the partials in order: lane l folds a contiguous slice, then lane 0 folds the 64 slices.
+__global__ __launch_bounds__(64) void adler32_combine_kernel(const uint32_t *partials, uint32_t nwaves, uint32_t init,
+                                                            uint64_t len, uint32_t tail_pad, uint32_t *out)
+{
+    __shared__ uint32_t sh[64 * 3];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t per = (nwaves + 63u) / 64u;
+    uint32_t SA = 0, SB = 0, N = 0;
+    for (uint32_t k = lane * per; k < (lane + 1) * per && k < nwaves; ++k) {
+        const uint32_t ya = partials[3 * k], yb = partials[3 * k + 1], yn = partials[3 * k + 2];
+        SB = (uint32_t)(((uint64_t)SB + (uint64_t)yn * SA + yb) % ADLER_MOD);
+        SA = (SA + ya) % ADLER_MOD;
+        N = (N + yn) % ADLER_MOD;
+    }
+    sh[3 * lane] = SA;
+    sh[3 * lane + 1] = SB;
+    sh[3 * lane + 2] = N;
+    __syncthreads();
+    if (lane == 0) {
+        SA = 0;
+        SB = 0;
+        for (uint32_t k = 0; k < 64; ++k) {
+            const uint32_t ya = sh[3 * k], yb = sh[3 * k + 1], yn = sh[3 * k + 2];
+            SB = (uint32_t)(((uint64_t)SB + (uint64_t)yn * SA + yb) % ADLER_MOD);
+            SA = (SA + ya) % ADLER_MOD;
+        }
+        // the zero bytes padding the last vector moved the end of the buffer by tail_pad: every weight is
+        // tail_pad too large, i.e. SB is tail_pad * SA too large
+        SB = (uint32_t)(((uint64_t)SB + (uint64_t)ADLER_MOD * 16u - (uint64_t)tail_pad * SA) % ADLER_MOD);
+        // start from `init` = (b0 << 16) | a0 :  A = a0 + SA ; B = b0 + len*a0 + SB   (Adler32.hs:22-27 unrolled)
+        const uint32_t a0 = init & 0xffffu, b0 = init >> 16;
+        const uint32_t A = (a0 + SA) % ADLER_MOD;
+        const uint32_t B = (uint32_t)(((uint64_t)b0 + (len % ADLER_MOD) * a0 + SB) % ADLER_MOD);
+        out[0] = (B << 16) | A;
+    }
+}
+
+hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *partials, uint32_t max_waves,
+                          uint32_t *out, hipStream_t stream)
+{
+    const uint32_t head_pad = (uint32_t)((uintptr_t)buf & 15u);
+    const uint8_t *abase = buf - head_pad;
+    const uint64_t padded = head_pad + len;
+    uint64_t nvec = (padded + 15u) >> 4;
+    uint32_t tail_valid = (uint32_t)(padded & 15u);
+    if (tail_valid == 0) tail_valid = 16;
+    if (len == 0) nvec = 0;
+    const uint64_t nblocks = (nvec + AD_BLOCK_VECS - 1) / AD_BLOCK_VECS;
+    uint64_t nwaves = nblocks < max_waves ? nblocks : max_waves;
+    if (nwaves == 0) nwaves = 1;
+    const uint32_t bpw = (uint32_t)((nblocks + nwaves - 1) / nwaves);
+    nwaves = nblocks ? (nblocks + bpw - 1) / bpw : 1;
+    const uint32_t wgs = (uint32_t)((nwaves + 3) / 4);
+    hipLaunchKernelGGL(adler32_partial_kernel, dim3(wgs), dim3(256), 0, stream, abase, nvec, head_pad, tail_valid,
+                       nblocks, bpw ? bpw : 1u, partials);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(adler32_combine_kernel, dim3(1), dim3(64), 0, stream, partials, wgs * 4u, init, len,
+                       16u - tail_valid, out);
+    return hipGetLastError();
+}
+
+}  // namespace pzg

@@ -1,0 +1,30 @@
+// pzg_launch.h -- kernel argument block and launcher prototypes shared by pzg_kernels.hip and pzg_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pzg {
+
+struct InflateArgs {
+    const uint8_t *in_base;
+    const uint64_t *in_off;   // n
+    const uint64_t *in_len;   // n
+    uint8_t *out_base;
+    const uint64_t *out_off;  // n
+    const uint64_t *out_cap;  // n
+    uint64_t *out_len;        // n
+    int32_t *status;          // n
+    uint32_t *detail;         // 2n or null
+    uint64_t *in_used;        // n or null
+    uint32_t *adler;          // n or null
+    const uint32_t *order;    // optional launch permutation (n) or null
+    uint32_t n;
+};
+
+hipError_t launch_inflate(const InflateArgs &a, int ring_bits, hipStream_t stream);
+
+// partials: 3 * 4 * ceil(max_waves / 4) uint32 of device scratch
+hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *partials, uint32_t max_waves,
+                          uint32_t *out, hipStream_t stream);
+
+}  // namespace pzg

@@ -1,0 +1,163 @@
+// wave.h -- the few wavefront primitives the inflate/adler kernels are written against.
+//
+// Device build (hipcc, gfx950): a wave is 64 lanes; wave-uniform values are pinned into
+// SGPRs with v_readfirstlane so the decode state machine runs on the scalar unit.
+//
+// Host build (plain g++, tests/model only): PZG_WAVE == 1.  The same source then executes
+// as a single-lane program, which lets the CPU test-suite fuzz the kernels' control logic,
+// table construction and error ordering without a GPU.  The host build is test
+// infrastructure: libpzg.so never contains or calls it (there is no CPU fallback).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PZG_FN __host__ __device__ __forceinline__
+#else
+#define PZG_FN inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PZG_DEVICE_PASS 1
+#define PZG_WAVE 64u
+#else
+#define PZG_DEVICE_PASS 0
+#define PZG_WAVE 1u
+#endif
+
+namespace pzg {
+
+PZG_FN uint32_t lane_id()
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#else
+    return 0u;
+#endif
+}
+
+// wave-uniform value -> SGPR
+PZG_FN uint32_t uni(uint32_t x)
+{
+#if PZG_DEVICE_PASS
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+#else
+    return x;
+#endif
+}
+
+PZG_FN uint64_t uni64(uint64_t x)
+{
+#if PZG_DEVICE_PASS
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+#else
+    return x;
+#endif
+}
+
+// value held by lane `l` (l wave-uniform)
+PZG_FN uint32_t read_lane(uint32_t v, uint32_t l)
+{
+#if PZG_DEVICE_PASS
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+#else
+    (void)l;
+    return v;
+#endif
+}
+
+PZG_FN uint64_t ballot(bool p)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_ballot_w64(p);
+#else
+    return p ? 1ull : 0ull;
+#endif
+}
+
+// number of set bits of m below this lane
+PZG_FN uint32_t mbcnt(uint64_t m)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+    (void)m;
+    return 0u;
+#endif
+}
+
+PZG_FN uint32_t popc64(uint64_t m) { return (uint32_t)__builtin_popcountll(m); }
+
+// Orders this wave's LDS traffic between cooperative phases.  The workgroup is exactly one
+// wave, so this is a compiler + lgkmcnt fence, not a multi-wave rendezvous.
+PZG_FN void wave_sync()
+{
+#if PZG_DEVICE_PASS
+    __syncthreads();
+#endif
+}
+
+// sum over the wave, result uniform
+PZG_FN uint32_t wave_sum(uint32_t x)
+{
+#if PZG_DEVICE_PASS
+    x += (uint32_t)__shfl_xor((int)x, 32);
+    x += (uint32_t)__shfl_xor((int)x, 16);
+    x += (uint32_t)__shfl_xor((int)x, 8);
+    x += (uint32_t)__shfl_xor((int)x, 4);
+    x += (uint32_t)__shfl_xor((int)x, 2);
+    x += (uint32_t)__shfl_xor((int)x, 1);
+    return uni(x);
+#else
+    return x;
+#endif
+}
+
+PZG_FN uint32_t wave_max(uint32_t x)
+{
+#if PZG_DEVICE_PASS
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t y = (uint32_t)__shfl_xor((int)x, o);
+        x = x > y ? x : y;
+    }
+    return uni(x);
+#else
+    return x;
+#endif
+}
+
+// sum of the four bytes of x, plus c
+PZG_FN uint32_t sum4(uint32_t x, uint32_t c)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_udot4(x, 0x01010101u, c, false);
+#else
+    return c + (x & 0xff) + ((x >> 8) & 0xff) + ((x >> 16) & 0xff) + (x >> 24);
+#endif
+}
+
+// dot product of the four bytes of x with the four bytes of w, plus c
+PZG_FN uint32_t dot4(uint32_t x, uint32_t w, uint32_t c)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_udot4(x, w, c, false);
+#else
+    return c + (x & 0xff) * (w & 0xff) + ((x >> 8) & 0xff) * ((w >> 8) & 0xff) +
+           ((x >> 16) & 0xff) * ((w >> 16) & 0xff) + (x >> 24) * (w >> 24);
+#endif
+}
+
+PZG_FN uint32_t bitrev32(uint32_t x)
+{
+#if defined(__clang__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    return __builtin_bswap32(x);
+#endif
+}
+
+} // namespace pzg

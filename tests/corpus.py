@@ -1,0 +1,95 @@
+"""Seeded synthetic corpora shared by the tests and bench.py.
+
+All compression is done with the system zlib (Python's `zlib`), which SURVEY.md section 0 item 3
+establishes as an independent, specification-equal encoder/decoder for valid streams.
+"""
+import random
+import zlib
+
+import numpy as np
+
+_ALPHA = b"abcdefghijklmnopqrstuvwxyz"
+
+
+def zipf_text(nbytes: int, seed: int, vocab: int = 4096, s: float = 1.1) -> bytes:
+    """Text-like data: a seeded vocabulary drawn Zipf(s), space-joined, newline every 256 words."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(2, 11, size=vocab)
+    letters = rng.integers(0, 26, size=int(lens.sum()))
+    words, p = [], 0
+    for L in lens:
+        words.append(bytes(_ALPHA[c] for c in letters[p:p + L]))
+        p += L
+    ranks = np.arange(1, vocab + 1, dtype=np.float64)
+    prob = ranks ** (-s)
+    prob /= prob.sum()
+    out = bytearray()
+    nwords = 0
+    while len(out) < nbytes:
+        idx = rng.choice(vocab, size=max(64, (nbytes - len(out)) // 5 + 16), p=prob)
+        for i in idx:
+            out += words[i]
+            nwords += 1
+            out += b"\n" if nwords % 256 == 0 else b" "
+    return bytes(out[:nbytes])
+
+
+def random_bytes(nbytes: int, seed: int) -> bytes:
+    return np.random.default_rng(seed).integers(0, 256, size=nbytes, dtype=np.uint8).tobytes()
+
+
+def mixed_data(nbytes: int, seed: int) -> bytes:
+    """One of: random, text, a run of one byte, a short repeating pattern with noise."""
+    kind = seed % 4
+    if kind == 0:
+        return random_bytes(nbytes, seed)
+    if kind == 1:
+        return zipf_text(nbytes, seed, vocab=256)
+    if kind == 2:
+        return bytes([seed % 251]) * nbytes
+    rng = random.Random(seed)
+    unit = b"ab" * 7 + bytes(rng.getrandbits(8) for _ in range(5))
+    return (unit * (nbytes // len(unit) + 1))[:nbytes]
+
+
+def compress_variant(data: bytes, seed: int) -> bytes:
+    """zlib stream with seeded level/strategy/window/memLevel and seeded flush points (multi-block)."""
+    rng = random.Random(seed)
+    lvl = rng.randint(0, 9)
+    strat = rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])
+    co = zlib.compressobj(lvl, zlib.DEFLATED, rng.randint(9, 15), rng.randint(1, 9), strat)
+    z, pos = b"", 0
+    while pos < len(data):
+        step = rng.randint(1, max(1, len(data)))
+        z += co.compress(data[pos:pos + step])
+        pos += step
+        if rng.random() < 0.3:
+            z += co.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+    return z + co.flush()
+
+
+def corrupt(z: bytes, seed: int) -> bytes:
+    rng = random.Random(seed)
+    b = bytearray(z)
+    mode = rng.randrange(3)
+    if mode == 0 and b:
+        for _ in range(rng.randint(1, 3)):
+            i = rng.randrange(len(b))
+            b[i] ^= 1 << rng.randrange(8)
+    elif mode == 1 and b:
+        b = b[:rng.randrange(len(b))]
+    elif b:
+        i = rng.randrange(len(b))
+        b[i:i + rng.randint(1, 4)] = bytes(rng.getrandbits(8) for _ in range(rng.randint(0, 4)))
+    return bytes(b)
+
+
+def fixed_blob(nbytes: int, seed: int) -> bytes:
+    """BASELINE config 3: level-1 with Z_FIXED so the block really is BTYPE=1."""
+    co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    return co.compress(zipf_text(nbytes, seed)) + co.flush()
+
+
+def level6_blob(nbytes: int, seed: int) -> bytes:
+    """BASELINE config 4/5: zlib.compress(text, 6): one dynamic block at these sizes."""
+    return zlib.compress(zipf_text(nbytes, seed), 6)

@@ -1,0 +1,53 @@
+// model_harness.cpp -- TEST INFRASTRUCTURE: compiles the kernel source (inflate_core.h) as a
+// one-lane host program (PZG_WAVE == 1) so the CPU test-suite can fuzz the kernel's control
+// logic, table construction and error ordering against the oracle without a GPU.
+// Never linked into libpzg.so; the product has no CPU path.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../pure_zlib_amd/csrc/inflate_core.h"
+
+struct pzm_result {
+    int32_t status;
+    uint32_t detail0, detail1, adler;
+    uint64_t out_len, in_used;
+};
+
+template <int RB>
+static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, pzm_result *r)
+{
+    auto *lds = (pzg::WaveLds<RB> *)aligned_alloc(16, sizeof(pzg::WaveLds<RB>));
+    memset(lds, 0xA5, sizeof(*lds));  // LDS is not zero-initialised on the device either
+    // pad the input on both sides: the bit reader loads whole aligned dwords
+    uint8_t *buf = (uint8_t *)malloc(in_len + 16);
+    memset(buf, 0xEE, in_len + 16);
+    memcpy(buf + 8, in, in_len);
+    pzg::Decoder<RB> dec(*lds);
+    pzg::StreamResult sr;
+    dec.run(buf + 8, in_len, out, cap, &sr);
+    r->status = sr.status;
+    r->detail0 = sr.detail0;
+    r->detail1 = sr.detail1;
+    r->adler = sr.adler;
+    r->out_len = sr.out_len;
+    r->in_used = sr.in_used;
+    free(buf);
+    free(lds);
+}
+
+extern "C" {
+
+int pzm_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, int ring_bits, pzm_result *r)
+{
+    if (ring_bits == 15) run_one<15>(in, in_len, out, cap, r);
+    else if (ring_bits == 13) run_one<13>(in, in_len, out, cap, r);
+    else return -1;
+    return 0;
+}
+
+uint32_t pzm_lds_bytes(int ring_bits)
+{
+    return ring_bits == 15 ? sizeof(pzg::WaveLds<15>) : sizeof(pzg::WaveLds<13>);
+}
+}
