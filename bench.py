@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""bench.py -- decompressed GiB/s of the batched zlib decompressor on MI355X.
+
+Metric (BASELINE.json): "decompressed GiB/s (whole node) on 64K level-6 zlib blobs; bit-exact vs ref".
+Workload at N=1: BASELINE config 4, 65,536 x 32 KiB dynamic-Huffman (level-6) blobs, one stream per
+wavefront, inputs and outputs resident in HBM when the timed region starts.  A "step" is one pass
+of pzg_decompress_many over the whole batch.  N>1: one process per GPU, every rank decodes its own
+65,536-stream shard of an N x 65,536 batch (weak scaling, no data-path collective).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch  # first: libpzg.so then binds to the HIP runtime torch already loaded
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import corpus  # noqa: E402
+import pure_zlib_amd as P  # noqa: E402
+from pure_zlib_amd.shard import plan_shards  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0  # same guide: float4 copy
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_pool(args):
+    """P distinct (text, zlib stream) pairs, seeds 0..P-1, identical on every rank."""
+    texts, zs = [], []
+    for seed in range(args.pool):
+        if args.workload == "fixed_4k":
+            t = corpus.zipf_text(4096, seed)
+            co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+            z = co.compress(t) + co.flush()
+        elif args.workload == "mixed":
+            size = 1024 * (1 + (seed * 2654435761 >> 7) % 64)
+            t = corpus.zipf_text(size, seed)
+            z = zlib.compress(t, 6)
+        else:
+            t = corpus.zipf_text(args.blob_bytes, seed)
+            z = zlib.compress(t, args.level)
+        texts.append(t)
+        zs.append(z)
+    return texts, zs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed"])
+    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
+    ap.add_argument("--blob-bytes", type=int, default=32768)
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--pool", type=int, default=2048, help="distinct blobs; the batch replicates them at distinct addresses")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="streams timed on the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--adler-gib", type=float, default=16.0, help="Adler-32 microbench size (BASELINE config 2); 0 = skip")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    t_setup = time.time()
+    texts, zs = build_pool(args)
+    npool = len(zs)
+    total_streams = args.streams * world
+    rng = np.random.default_rng(0xB00C)
+    perm = rng.integers(0, npool, size=total_streams)  # which pool blob stream g replicates
+    dec_len = np.array([len(t) for t in texts], dtype=np.int64)
+    shards = plan_shards(dec_len[perm], world)
+    mine = shards[rank]
+    n = len(mine)
+    pick = perm[mine]
+
+    # arenas: every stream at its own 256-byte aligned address (footprint >> 256 MiB Infinity Cache)
+    zlen = np.array([len(z) for z in zs], dtype=np.int64)
+    in_len = zlen[pick]
+    out_cap = dec_len[pick]
+    in_off = np.zeros(n, dtype=np.int64)
+    out_off = np.zeros(n, dtype=np.int64)
+    in_off[1:] = np.cumsum((in_len[:-1] + 255) // 256 * 256)
+    out_off[1:] = np.cumsum((out_cap[:-1] + 255) // 256 * 256)
+    in_bytes = int(in_off[-1] + (in_len[-1] + 255) // 256 * 256)
+    out_bytes = int(out_off[-1] + (out_cap[-1] + 255) // 256 * 256)
+    h_in = np.zeros(in_bytes, dtype=np.uint8)
+    zarr = [np.frombuffer(z, dtype=np.uint8) for z in zs]
+    for k in range(n):
+        h_in[in_off[k]:in_off[k] + in_len[k]] = zarr[pick[k]]
+    d_in = torch.from_numpy(h_in).to(dev)
+    d_out = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+    as_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)  # noqa: E731
+    d_in_off, d_in_len, d_out_off, d_out_cap = as_dev(in_off), as_dev(in_len), as_dev(out_off), as_dev(out_cap)
+    d_out_len = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_in_used = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    d_adler = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_detail = torch.zeros(2 * n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"[bench] setup {time.time() - t_setup:.1f}s: {n} streams/GPU, in {in_bytes / 2**20:.0f} MiB, "
+            f"out {out_bytes / 2**20:.0f} MiB, pool {npool}")
+
+    ctx = P.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        ctx.decompress_many_device(d_in.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), d_out.data_ptr(),
+                                   d_out_off.data_ptr(), d_out_cap.data_ptr(), d_out_len.data_ptr(),
+                                   d_status.data_ptr(), d_detail.data_ptr(), d_in_used.data_ptr(), d_adler.data_ptr(),
+                                   n, sync=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(ctx.last_kernel_ms())  # HIP events on the launch stream (waits for the step)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- verification: EVERY stream of the timed batch, bit-exact ---------------------------------
+    status = d_status.cpu().numpy()
+    out_len = d_out_len.cpu().numpy()
+    adler = d_adler.cpu().numpy().view(np.uint32)
+    bit_exact = None
+    if not args.no_verify:
+        exp_adler = np.array([zlib.adler32(t) for t in texts], dtype=np.uint32)[pick]
+        ok = bool((status == 0).all() and (out_len == out_cap).all() and (adler == exp_adler).all()
+                  and (d_in_used.cpu().numpy() == in_len).all())
+        if ok and len(set(dec_len.tolist())) == 1:
+            # full byte compare on the device: out arena vs the expected texts gathered the same way
+            width = int(dec_len[0])
+            stride = (width + 255) // 256 * 256
+            pool_t = torch.from_numpy(np.frombuffer(b"".join(texts), dtype=np.uint8).reshape(npool, width)).to(dev)
+            got = d_out.view(n, stride)[:, :width]
+            idx = torch.from_numpy(pick).to(dev)
+            for lo in range(0, n, 8192):
+                ok = ok and bool(torch.equal(got[lo:lo + 8192], pool_t[idx[lo:lo + 8192]]))
+        elif ok:
+            h_out = d_out.cpu().numpy()
+            for k in range(0, n):
+                if h_out[out_off[k]:out_off[k] + out_cap[k]].tobytes() != texts[pick[k]]:
+                    ok = False
+                    break
+        bit_exact = ok
+        if world > 1:
+            tt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            bit_exact = bool(tt.item())
+        if not bit_exact:
+            bad = np.nonzero(status != 0)[0]
+            log(f"[bench] rank {rank}: VERIFICATION FAILED; {len(bad)} bad statuses, first {bad[:5]} {status[bad[:5]]}")
+
+    dec_total = int(out_cap.sum()) * world  # decoded bytes per step, whole job (every rank holds the same amount)
+    comp_total = int(in_len.sum())
+    value = dec_total * args.steps / elapsed / 2**30
+
+    result = None
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        algo_bytes = comp_total + int(out_cap.sum())  # per launch on this GPU: compressed read once + decoded written once
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        result = {
+            "metric": "decompressed GiB/s (whole node) on 64K level-6 zlib blobs; bit-exact vs ref",
+            "value": round(value, 3),
+            "unit": "GiB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "bit_exact": bit_exact,
+            "config": {
+                "workload": {
+                    "l6_32k": f"BASELINE config 4: {args.streams} x {args.blob_bytes // 1024} KiB level-{args.level} "
+                              "dynamic-Huffman zlib blobs per GPU, one stream per wavefront, 32 KiB LDS ring",
+                    "fixed_4k": f"BASELINE config 3: {args.streams} x 4 KiB fixed-Huffman (Z_FIXED level-1) blobs per GPU",
+                    "mixed": f"BASELINE config 5 shape: {args.streams} mixed 1-64 KiB level-6 blobs per GPU",
+                }[args.workload],
+                "streams_per_gpu": n,
+                "distinct_blobs": npool,
+                "compressed_MiB_per_gpu": round(comp_total / 2**20, 1),
+                "decompressed_MiB_per_gpu": round(int(out_cap.sum()) / 2**20, 1),
+                "parallelism": f"shard{world}" if world > 1 else "single",
+                "verified": "every stream: status, length, in_used, Adler-32 and full byte compare" if bit_exact is not None else "skipped",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "inflate_kernel<15>",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "frac_of_measured_copy_6290": round(achieved / HBM_MEASURED_GBS, 5),
+                "read_only_GBps": round(comp_total / (k_ms * 1e-3) / 1e9, 2),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms_avg": round(k_ms, 4),
+                "traffic": None,
+            },
+        }
+
+    # ---- CPU baseline: the oracle ("port") on a bounded sample, rank 0 at N=1 only -----------------
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import oracle as O
+        m = min(args.cpu_sample, n)
+        s_in_off = in_off[:m].astype(np.uint64)
+        s_in_end = (in_off[:m] + in_len[:m]).astype(np.uint64)
+        # oracle's batch helper takes (off[n+1]) extents: build per-stream pairs
+        L = O.lib()
+        obuf = np.zeros(int(out_cap[:m].max()) + 64, dtype=np.uint8)
+        res = O.Result()
+        t0c = time.perf_counter()
+        nbytes = 0
+        for k in range(m):
+            L.pzo_decompress(h_in.ctypes.data + int(s_in_off[k]), int(s_in_end[k] - s_in_off[k]),
+                             obuf.ctypes.data, int(out_cap[k]), res)
+            nbytes += res.out_len
+            if res.status != 0:
+                raise SystemExit("oracle rejected a bench stream")
+        dtc = time.perf_counter() - t0c
+        t0z = time.perf_counter()
+        for k in range(m):
+            zlib.decompress(h_in[int(s_in_off[k]):int(s_in_end[k])].tobytes())
+        dtz = time.perf_counter() - t0z
+        result["cpu_baseline"] = {
+            "value": round(nbytes / dtc / 2**30, 4),
+            "unit": "GiB/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"first {m} streams of the same batch ({nbytes / 2**20:.0f} MiB decoded) through oracle/pz_oracle.c "
+                      f"(bit-at-a-time restatement of pure-zlib), 1 thread, {dtc:.1f}s",
+            "host_cores_available": os.cpu_count(),
+            "system_zlib_1thread_GiBps": round(nbytes / dtz / 2**30, 3),
+            "note": "the Haskell reference itself cannot run here (no GHC); README.md:6-8 puts it ~100x below C zlib",
+        }
+
+    # ---- BASELINE config 2: Adler-32 over one large buffer (HBM-bound microbench) -------------------
+    if rank == 0 and world == 1 and args.adler_gib > 0:
+        nb = int(args.adler_gib * 2**30)
+        free, _tot = torch.cuda.mem_get_info()
+        nb = min(nb, int(free * 0.8))
+        buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5EED0002)
+        chunk = 1 << 28
+        for lo in range(0, nb, chunk):
+            hi = min(nb, lo + chunk)
+            buf[lo:hi] = torch.randint(0, 256, (hi - lo,), dtype=torch.uint8, device=dev, generator=g)
+        d_res = torch.zeros(1, dtype=torch.int32, device=dev)
+        for _ in range(2):
+            ctx.adler32_device(buf.data_ptr(), nb, d_res.data_ptr(), sync=True)
+        ms = []
+        for _ in range(10):
+            ctx.adler32_device(buf.data_ptr(), nb, d_res.data_ptr(), sync=True)
+            ms.append(ctx.last_kernel_ms())
+        got = int(d_res.cpu().numpy().view(np.uint32)[0])
+        exp = 1
+        for lo in range(0, nb, chunk):
+            exp = zlib.adler32(buf[lo:lo + chunk].cpu().numpy().tobytes(), exp)
+        med = float(np.median(ms))
+        result["adler32_microbench"] = {
+            "workload": f"BASELINE config 2: Adler-32 over one {nb / 2**30:.1f} GiB device buffer",
+            "GBps": round(nb / (med * 1e-3) / 1e9, 1),
+            "frac_of_8000": round(nb / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_of_measured_copy_6290": round(nb / (med * 1e-3) / 1e9 / HBM_MEASURED_GBS, 4),
+            "kernel_ms_median": round(med, 3),
+            "matches_zlib_adler32": bool(got == exp),
+        }
+        del buf
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if bit_exact is False:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

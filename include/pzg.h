@@ -79,9 +79,11 @@ typedef struct pzg_ctx pzg_ctx;
 int  pzg_init(int device, pzg_ctx **out);
 void pzg_shutdown(pzg_ctx *ctx);
 
-/* Make the context launch on an existing HIP stream (e.g. a framework's current stream)
- * instead of its own.  `hip_stream` is a hipStream_t passed as void*; NULL restores the own stream. */
+/* Make the context launch on an existing HIP stream (e.g. a framework's current stream) instead of
+ * its own.  `hip_stream` is a hipStream_t passed as void*; NULL means HIP's default (null) stream.
+ * pzg_reset_stream() goes back to the context's own non-blocking stream. */
 int  pzg_set_stream(pzg_ctx *ctx, void *hip_stream);
+int  pzg_reset_stream(pzg_ctx *ctx);
 int  pzg_sync(pzg_ctx *ctx);
 
 /*

@@ -123,7 +123,15 @@ int pzg_set_stream(pzg_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return PZG_RC_BAD_ARG;
     std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;  // NULL = the default (null) stream
+    return PZG_RC_OK;
+}
+
+int pzg_reset_stream(pzg_ctx *ctx)
+{
+    if (!ctx) return PZG_RC_BAD_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stream = ctx->own_stream;
     return PZG_RC_OK;
 }
 

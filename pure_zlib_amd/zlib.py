@@ -159,7 +159,11 @@ class Context:
         return self._h
 
     def set_stream(self, hip_stream: Optional[int]):
+        """Launch on an existing hipStream_t (integer handle; 0/None = HIP's default stream)."""
         _ffi.check(self._L.pzg_set_stream(self._h, C.c_void_p(hip_stream or 0)), self._h)
+
+    def reset_stream(self):
+        _ffi.check(self._L.pzg_reset_stream(self._h), self._h)
 
     def sync(self):
         _ffi.check(self._L.pzg_sync(self._h), self._h)

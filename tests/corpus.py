@@ -11,27 +11,43 @@ import numpy as np
 _ALPHA = b"abcdefghijklmnopqrstuvwxyz"
 
 
+_VOCAB_CACHE = {}
+
+
+def _vocab(vocab: int, s: float):
+    """Seed-independent vocabulary (fixed seed 0x5EED): word matrix [vocab, 11] (trailing sep slot), lengths, Zipf CDF."""
+    key = (vocab, s)
+    if key not in _VOCAB_CACHE:
+        rng = np.random.default_rng(0x5EED)
+        lens = rng.integers(2, 11, size=vocab)
+        mat = np.frombuffer(_ALPHA, dtype=np.uint8)[rng.integers(0, 26, size=(vocab, 11))].copy()
+        ranks = np.arange(1, vocab + 1, dtype=np.float64)
+        prob = ranks ** (-s)
+        cdf = np.cumsum(prob / prob.sum())
+        _VOCAB_CACHE[key] = (mat, lens.astype(np.int64), cdf)
+    return _VOCAB_CACHE[key]
+
+
 def zipf_text(nbytes: int, seed: int, vocab: int = 4096, s: float = 1.1) -> bytes:
-    """Text-like data: a seeded vocabulary drawn Zipf(s), space-joined, newline every 256 words."""
+    """Text-like data: words of a fixed 4096-word vocabulary drawn Zipf(1.1) with a
+    per-blob seed, space-joined, newline every 256 words.  Vectorised: ~1 ms per 32 KiB."""
+    if nbytes == 0:
+        return b""
+    mat, wl, cdf = _vocab(vocab, s)
     rng = np.random.default_rng(seed)
-    lens = rng.integers(2, 11, size=vocab)
-    letters = rng.integers(0, 26, size=int(lens.sum()))
-    words, p = [], 0
-    for L in lens:
-        words.append(bytes(_ALPHA[c] for c in letters[p:p + L]))
-        p += L
-    ranks = np.arange(1, vocab + 1, dtype=np.float64)
-    prob = ranks ** (-s)
-    prob /= prob.sum()
-    out = bytearray()
-    nwords = 0
-    while len(out) < nbytes:
-        idx = rng.choice(vocab, size=max(64, (nbytes - len(out)) // 5 + 16), p=prob)
-        for i in idx:
-            out += words[i]
-            nwords += 1
-            out += b"\n" if nwords % 256 == 0 else b" "
-    return bytes(out[:nbytes])
+    nw = nbytes // 3 + 8  # shortest word + separator is 3 bytes
+    idx = np.searchsorted(cdf, rng.random(nw)).clip(0, vocab - 1)
+    lens = wl[idx] + 1  # + separator
+    ends = np.cumsum(lens)
+    starts = ends - lens
+    total = int(ends[-1])
+    word_of = np.repeat(np.arange(nw), lens)
+    ch = np.arange(total) - starts[word_of]
+    out = mat[idx[word_of], np.minimum(ch, 10)]
+    sep_pos = ends - 1
+    out[sep_pos] = 0x20
+    out[sep_pos[255::256]] = 0x0A
+    return out[:nbytes].tobytes()
 
 
 def random_bytes(nbytes: int, seed: int) -> bytes:
