@@ -1,28 +1,41 @@
 // inflate_core.h -- one zlib stream decoded by one wavefront.
 //
 // MI355X counterpart of pure-zlib's whole decode stack:
-//   Zlib.hs:53-69      inflateWithHeaders   -> inflate_stream() prologue
-//   Deflate.hs:39-63   inflate/checkChecksum-> inflate_stream() block loop + trailer
-//   Deflate.hs:65-104  inflateBlock         -> stored_block() / dynamic_header() / fixed tables
-//   Deflate.hs:106-120 runInflate           -> token_loop()
+//   Zlib.hs:53-69      inflateWithHeaders   -> Decoder::decode() prologue
+//   Deflate.hs:39-63   inflate/checkChecksum-> Decoder::decode() block loop + trailer
+//   Deflate.hs:65-104  inflateBlock         -> stored_block() / dynamic_header() / load_fixed_tables()
+//   Deflate.hs:106-120 runInflate           -> token_loop(): window_step() + token_step_checked()
 //   Deflate.hs:124-156 getCodeLengths       -> dynamic_header()
 //   Deflate.hs:160-237 length/distance arrays -> litlen_entry()/dist_entry() (closed forms)
 //   Deflate.hs:255-292 computeCodeValues    -> build_table() (canonical codes, wave-parallel)
 //   HuffmanTree.hs     binary trie          -> two-level LDS table: a direct 2^P LUT indexed by the
 //                                             next P stream bits, then a canonical first-code/count
 //                                             table + symbol permutation for codes longer than P
-//   Monad.hs:203-307   bit/byte reader      -> BitReader (coalesced dword loads, 64-bit wave-uniform
-//                                             bit buffer in SGPRs, per-wave bit cursor)
+//   Monad.hs:203-307   bit/byte reader      -> BitReader: coalesced dword chunks held one dword per
+//                                             lane, a per-wave bit cursor, v_readlane to fetch
 //   OutputWindow.hs    128 KiB flat window  -> 2^RING_BITS LDS ring, lane-cooperative LZ77 copy
 //   Adler32.hs         per-byte checksum    -> folded into the ring->HBM flush as a wave reduction
 //
-// All decode state is wave-uniform; the 64 lanes cooperate on table construction, match
-// copies, stored-block copies and the flush.  The same source compiles as a one-lane host
-// program for the CPU model tests (see wave.h).
+// The hot loop (window_step) is wave-parallel: lane k speculatively decodes the complete token
+// (literal, or length + distance with their extra bits) that would start k bits ahead of the
+// cursor -- two LDS lookups for all 64 offsets at once -- and a scalar walk then follows the real
+// chain from offset 0 with v_readlane, so no LDS round trip is paid per token.  Literal runs are
+// stored by all their lanes in one ds_write_b8; matches are lane-cooperative ring copies.
+//
+// The same source compiles as a host program for the CPU model tests (see wave.h).
 #pragma once
 #include <stdint.h>
 
 #include "wave.h"
+
+// Diagnostic build only (-DPZG_PROFILE): per-phase cycle stamps; never compiled into libpzg.so.
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+#define PZG_T0(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#define PZG_ACC(slot, var) prof[slot] += __builtin_amdgcn_s_memtime() - var
+#else
+#define PZG_T0(var)
+#define PZG_ACC(slot, var)
+#endif
 
 namespace pzg {
 
@@ -121,9 +134,12 @@ struct alignas(16) WaveLds {
     uint16_t dist_sorted[MAX_DIST_SYMS + 6];
     TreeMeta lit_meta;
     TreeMeta dist_meta;
-    uint32_t cnt[16];                    // histogram scratch for build_table
+    TreeMeta cl_meta;
+    uint32_t cnt[16];                    // histogram / running-rank scratch for build_table
     uint8_t lens[MAX_LENS + 22];         // code lengths of the block being set up
     uint8_t cl_lens[20];                 // code-length code lengths in symbol order
+    uint8_t mk[64];                      // window_step's byte->token marker; all zero between segments
+    uint8_t dump[64 + 12];               // where masked-off lanes store (see sel_store): keeps hot loops free of lane-dependent branches
 };
 
 // ---- result of one stream -------------------------------------------------------------------
@@ -136,20 +152,34 @@ struct StreamResult {
 };
 
 // ---- Monad.hs:203-307: the bit reader ---------------------------------------------------------
-// Each lane holds one dword of the current PZG_WAVE-dword input chunk (one coalesced load per
-// chunk, the next chunk prefetched); the wave-uniform 64-bit bit buffer is fed from it with
-// v_readlane.  Bits are consumed LSB-first (Monad.hs:224-230).
+// The compressed stream is read as aligned dwords, 64 at a time: lane l of `cur` holds dword
+// chunk0+l (one fully coalesced 256-byte load per chunk), `nxt` the following chunk, prefetched.
+// `pos` is the per-wave bit cursor; dword(i) fetches a wave-uniform dword with v_readlane.
+// Bits are consumed LSB-first (Monad.hs:224-230).
 struct BitReader {
     const uint32_t *base;  // 4-byte aligned address at or below the stream start
     uint32_t ndw;          // dwords covering [base, stream end)
     uint32_t mis_bits;     // 8 * (stream start - base)
     uint64_t end_rel;      // mis_bits + 8 * stream length: first bit (relative to base) past the stream
-    uint64_t buf;          // wave-uniform
-    uint32_t cnt;          // valid bits in buf
-    uint32_t next;         // next dword index to feed
-    uint32_t cur, nxt;     // per-lane: dwords of the current / next chunk
+    uint64_t pos;          // next unread bit, relative to base
+#if PZG_DEVICE_PASS
+    uint32_t chunk0;       // dword index held by lane 0 of `cur` (multiple of 64)
+    uint32_t cur, nxt;     // per-lane
+#endif
 
     PZG_FN uint32_t load_dw(uint32_t i) const { return i < ndw ? base[i] : 0u; }
+
+    // lane l's dword of the 64-dword chunk starting at c0 (wave-uniform), zero past the stream.
+    // Branch-free per lane (clamped index + select): a lane-dependent branch here would sit inside
+    // the loops that carry the wave-uniform decoder state and make the compiler treat that state as
+    // divergent (VALU + exec-mask loops instead of SALU + s_cbranch).
+    PZG_FN uint32_t load_chunk(uint32_t c0) const
+    {
+        if (c0 >= ndw) return 0u;  // wave-uniform
+        const uint32_t i = c0 + lane_id();
+        const uint32_t v = base[i < ndw ? i : ndw - 1u];
+        return i < ndw ? v : 0u;
+    }
 
     PZG_FN void start(const uint8_t *in, uint64_t in_len, uint64_t byte_pos)
     {
@@ -160,41 +190,51 @@ struct BitReader {
         mis_bits = mis * 8u;
         ndw = (uint32_t)((mis + remain + 3u) >> 2);
         end_rel = (uint64_t)mis_bits + remain * 8u;
-        uint32_t l = lane_id();
-        cur = load_dw(l);
-        nxt = load_dw(PZG_WAVE + l);
-        next = 0;
-        buf = 0;
-        cnt = 0;
-        refill();
-        buf >>= mis_bits;  // cnt >= 33 > 24 >= mis_bits
-        cnt -= mis_bits;
+        pos = mis_bits;
+#if PZG_DEVICE_PASS
+        chunk0 = 0;
+        cur = load_chunk(0u);
+        nxt = load_chunk(64u);
+#endif
     }
 
-    PZG_FN void refill()
+    // wave-uniform dword i; on the device i must lie in [chunk0, chunk0 + 128)
+    PZG_FN uint32_t dword(uint32_t i) const
     {
-        while (cnt <= 32u) {
-            uint32_t d = read_lane(cur, next & (PZG_WAVE - 1u));
-            buf |= (uint64_t)d << cnt;
-            cnt += 32u;
-            next++;
-            if ((next & (PZG_WAVE - 1u)) == 0u) {
-                cur = nxt;
-                nxt = load_dw(next + PZG_WAVE + lane_id());
-            }
-        }
+#if PZG_DEVICE_PASS
+        const uint32_t a = read_lane(cur, i & 63u), b = read_lane(nxt, i & 63u);
+        return (i - chunk0) < 64u ? a : b;
+#else
+        return load_dw(i);
+#endif
     }
 
-    // bit position of the next unread bit, relative to `base`
-    PZG_FN uint64_t pos_rel() const { return (uint64_t)next * 32u - cnt; }
-    // real (in-stream) bits still unread; <= 0 means everything in buf is padding
-    PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos_rel(); }
-    PZG_FN uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+    // keep the cursor's dword inside `cur`
+    PZG_FN void slide()
+    {
+#if PZG_DEVICE_PASS
+        while ((uint32_t)(pos >> 5) - chunk0 >= 64u) {
+            cur = nxt;
+            chunk0 += 64u;
+            nxt = load_chunk(chunk0 + 64u);
+        }
+#endif
+    }
+
+    PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos; }
+
+    // the next 32 bits (bits past the stream end read as whatever follows; callers check avail())
+    PZG_FN uint32_t peek32() const
+    {
+        const uint32_t i = (uint32_t)(pos >> 5);
+        return funnel(dword(i + 1u), dword(i), (uint32_t)pos & 31u);
+    }
     PZG_FN void drop(uint32_t n)
     {
-        buf >>= n;
-        cnt -= n;
+        pos += n;
+        slide();
     }
+    PZG_FN void align_to_byte() { drop((uint32_t)(8u - ((uint32_t)pos & 7u)) & 7u); }
 };
 
 // ---- decoder state (all wave-uniform) -----------------------------------------------------------
@@ -202,7 +242,8 @@ template <int RING_BITS>
 struct Decoder {
     static constexpr uint32_t RING = 1u << RING_BITS;
     static constexpr uint32_t RMASK = RING - 1u;
-    static constexpr uint32_t FLUSH_AT = RING - 512u;
+    static constexpr uint32_t FLUSH_AT = RING - 1024u;
+    static constexpr int WINDOW_MIN_BITS = 192;  // 5 dwords + slack: every token of a window is real data
 
     WaveLds<RING_BITS> &L;
     const uint8_t *in;
@@ -210,7 +251,7 @@ struct Decoder {
     uint8_t *out;
     uint64_t cap;
     BitReader br;
-    uint64_t in_byte0;  // byte offset of br.base's stream start (br was started at this byte position)
+    uint64_t in_byte0;  // byte offset in the stream at which br was (re)started
     uint64_t op;        // bytes produced
     uint64_t flushed;   // bytes already written to HBM and folded into the Adler state
     uint32_t adler_a, adler_b;
@@ -218,8 +259,34 @@ struct Decoder {
     int fixed_loaded;            // lit/dist tables currently hold the fixed code
     int32_t status;
     uint32_t detail0, detail1;
+#if defined(PZG_PROFILE)
+    uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0 total, 1 header+tables, 2 token loop, 3 flush, 4 window_step, 5 checked steps, 6 windows, 7 matches
+#endif
 
     PZG_FN Decoder(WaveLds<RING_BITS> &lds) : L(lds) {}
+
+    // Pin every piece of wave-uniform decoder state back into SGPRs.  All of it IS uniform by
+    // construction; this only tells the compiler so (v_readfirstlane of an SGPR value folds away),
+    // so the state machine is compiled to SALU + s_cbranch instead of VALU + exec-mask loops.
+    PZG_FN void pin_uniform()
+    {
+#if PZG_DEVICE_PASS
+        br.pos = uni64(br.pos);
+        br.chunk0 = uni(br.chunk0);
+        br.end_rel = uni64(br.end_rel);
+        br.ndw = uni(br.ndw);
+        br.mis_bits = uni(br.mis_bits);
+        op = uni64(op);
+        flushed = uni64(flushed);
+        adler_a = uni(adler_a);
+        adler_b = uni(adler_b);
+        lit_e15 = uni(lit_e15);
+        dist_e15 = uni(dist_e15);
+        fixed_loaded = (int)uni((uint32_t)fixed_loaded);
+        in_byte0 = uni64(in_byte0);
+        status = (int32_t)uni((uint32_t)status);
+#endif
+    }
 
     PZG_FN int fail(int32_t st, uint32_t d0, uint32_t d1)
     {
@@ -230,7 +297,7 @@ struct Decoder {
     }
 
     // absolute bit offset of the next unread bit within the stream
-    PZG_FN uint64_t stream_bit_pos() const { return in_byte0 * 8u + br.pos_rel() - br.mis_bits; }
+    PZG_FN uint64_t stream_bit_pos() const { return in_byte0 * 8u + br.pos - br.mis_bits; }
 
     // ---- OutputWindow.hs + Adler32.hs: ring -> HBM flush with the checksum folded in ------------
     // Writes produced bytes [flushed, to) and advances the Adler state over them.  `flushed` is
@@ -238,6 +305,7 @@ struct Decoder {
     // addresses are 16-byte aligned: one ds_read_b128 + one global_store_dwordx4 per lane.
     PZG_FN void flush_to(uint64_t to)
     {
+        PZG_T0(tf);
         wave_sync();
         const uint64_t from = flushed;
         if (to <= from) return;
@@ -280,8 +348,8 @@ struct Decoder {
 #endif
                 } else {
                     const uint32_t xs[4] = {x0, x1, x2, x3};
-                    for (uint32_t k = 0; k < valid; ++k)
-                        if (pos + k < cap) out[pos + k] = (uint8_t)(xs[k >> 2] >> (8u * (k & 3u)));
+                    for (uint32_t k = 0; k < 16u; ++k)  // fixed trip count: no lane-dependent loop exit
+                        if (k < valid && pos + k < cap) out[pos + k] = (uint8_t)(xs[k >> 2] >> (8u * (k & 3u)));
                 }
                 // Adler32.hs:29-34 advanceNoMod over 16 bytes at once: s = sum d_i, t = sum (16-i) d_i
                 uint32_t s = sum4(x0, sum4(x1, sum4(x2, sum4(x3, 0u))));
@@ -304,6 +372,7 @@ struct Decoder {
         adler_b = (uint32_t)(nb % ADLER_MOD);
         flushed = to;
         wave_sync();
+        PZG_ACC(3, tf);
     }
 
     PZG_FN void maybe_flush()
@@ -311,10 +380,21 @@ struct Decoder {
         if (op - flushed >= FLUSH_AT) flush_to(op & ~(uint64_t)15u);
     }
 
+    // Lane-predicated LDS byte store WITHOUT a branch: lanes whose predicate is false store into a
+    // per-lane dump byte instead.  A lane-dependent branch inside the loops that carry the
+    // wave-uniform decoder state makes hipcc treat that state as divergent (VALU + exec-mask loops
+    // instead of SALU + s_cbranch); a select on the address does not.
+    PZG_FN void sel_store(bool pred, uint8_t *dst, uint8_t v, uint32_t lane)
+    {
+        uint8_t *p = pred ? dst : &L.dump[lane & 63u];
+        *p = v;
+    }
+
     // Monad.hs:309-315 emitByte -> OutputWindow.hs:64-68 addByte
     PZG_FN void put_literal(uint32_t v)
     {
-        if (lane_id() == 0u) L.ring[(uint32_t)op & RMASK] = (uint8_t)v;
+        const uint32_t lane = lane_id();
+        sel_store(lane == 0u, &L.ring[(uint32_t)op & RMASK], (uint8_t)v, lane);
         op++;
     }
 
@@ -324,10 +404,16 @@ struct Decoder {
     // pieces), i.e. op-dist+(k mod dist).  So all reads are issued before any write.
     PZG_FN void copy_match(uint32_t dist, uint32_t len)
     {
-        constexpr uint32_t MAXCH = (258u + PZG_WAVE - 1u) / PZG_WAVE;
         const uint32_t lane = lane_id();
         const uint32_t src0 = (uint32_t)op - dist;
         const uint32_t dst0 = (uint32_t)op;
+        if (len <= PZG_WAVE && dist >= len) {  // the common case: one read, one write
+            const uint8_t v = L.ring[(src0 + lane) & RMASK];  // lanes >= len read a harmless ring byte
+            sel_store(lane < len, &L.ring[(dst0 + lane) & RMASK], v, lane);
+            op += len;
+            return;
+        }
+        constexpr uint32_t MAXCH = (258u + PZG_WAVE - 1u) / PZG_WAVE;
         uint8_t v[MAXCH];
         const bool overlap = dist < len;
 #if PZG_DEVICE_PASS
@@ -336,24 +422,24 @@ struct Decoder {
 #pragma unroll
         for (uint32_t c = 0; c < MAXCH; ++c) {
             const uint32_t k = c * PZG_WAVE + lane;
-            if (c * PZG_WAVE < len && k < len) {
+            if (c * PZG_WAVE < len) {  // wave-uniform
                 uint32_t off = k;
                 if (overlap) {
 #if PZG_DEVICE_PASS
                     uint32_t q = (uint32_t)(((float)k + 0.5f) * rd);
                     off = k - q * dist;
-                    if (off >= dist) off -= dist;
+                    off = off >= dist ? off - dist : off;
 #else
                     off = k % dist;
 #endif
                 }
-                v[c] = L.ring[(src0 + off) & RMASK];
+                v[c] = L.ring[(src0 + (k < len ? off : 0u)) & RMASK];
             }
         }
 #pragma unroll
         for (uint32_t c = 0; c < MAXCH; ++c) {
             const uint32_t k = c * PZG_WAVE + lane;
-            if (c * PZG_WAVE < len && k < len) L.ring[(dst0 + k) & RMASK] = v[c];
+            if (c * PZG_WAVE < len) sel_store(k < len, &L.ring[(dst0 + k) & RMASK], v[c], lane);
         }
         op += len;
     }
@@ -369,11 +455,13 @@ struct Decoder {
         const uint32_t lane = lane_id();
         // pass 1: histogram of code lengths (blCount, Deflate.hs:266)
         wave_sync();
-        if (lane < 16u || PZG_WAVE == 1u)
-            for (uint32_t i = lane; i < 16u; i += PZG_WAVE) L.cnt[i] = 0u;
+        if (lane < 16u) L.cnt[lane] = 0u;
+        if (PZG_WAVE == 1u)
+            for (uint32_t i = 1; i < 16u; ++i) L.cnt[i] = 0u;
         wave_sync();
-        for (uint32_t s = lane; s < n; s += PZG_WAVE) {
-            uint32_t len = lens[s];
+        for (uint32_t s0 = 0; s0 < n; s0 += PZG_WAVE) {  // every loop here has a wave-uniform trip count
+            const uint32_t s = s0 + lane;
+            const uint32_t len = s < n ? lens[s] : 0u;
 #if PZG_DEVICE_PASS
             if (len) atomicAdd(&L.cnt[len], 1u);
 #else
@@ -381,90 +469,70 @@ struct Decoder {
 #endif
         }
         wave_sync();
-        // next_code (step2, Deflate.hs:273-278), offsets, Kraft sum; all wave-uniform
-        uint32_t count[16], first[16], offs[16];
-        uint32_t code = 0, off = 0, e15 = 0, maxlen = 0;
-        count[0] = 0;
-        first[0] = 0;
-        offs[0] = 0;
-#pragma unroll
+        // next_code (step2, Deflate.hs:273-278), offsets, Kraft sum; wave-uniform, kept in LDS (meta)
+        uint32_t code = 0, prev = 0, off = 0, e15 = 0, covered_p = 0;
+#pragma nounroll
         for (uint32_t l = 1; l < 16u; ++l) {
-            uint32_t c = uni(L.cnt[l]);
-            count[l] = c;
-            code = (code + count[l - 1]) << 1;
-            first[l] = code;
-            offs[l] = off;
+            const uint32_t c = uni(L.cnt[l]);
+            code = (code + prev) << 1;
+            prev = c;
+            if (lane == 0u) {
+                meta->count[l] = (uint16_t)c;
+                meta->first[l] = (uint16_t)code;
+                meta->offs[l] = (uint16_t)off;
+                L.cnt[l] = 0u;  // becomes the running rank of pass 2
+            }
             off += c;
             e15 += c << (15u - l);
-            if (c) maxlen = l;
+            if (l == (uint32_t)P) covered_p = code + c;  // P-bit prefixes covered by codes of length <= P: [0, covered_p)
         }
         *e15_out = e15;
         if (e15 > 32768u) return false;  // over-subscribed: some insertion must collide
-        if (meta) {
-            for (uint32_t l = lane; l < 16u; l += PZG_WAVE) {
-                // per-lane select from the uniform arrays without dynamic register indexing
-                uint32_t c = 0, f = 0, o = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < 16u; ++q) {
-                    if (q == l) {
-                        c = count[q];
-                        f = first[q];
-                        o = offs[q];
-                    }
-                }
-                meta->count[l] = (uint16_t)c;
-                meta->first[l] = (uint16_t)f;
-                meta->offs[l] = (uint16_t)o;
-            }
-        }
+        wave_sync();
         // default fill: patterns no code of length <= P covers are either the prefix of a longer
         // code (K_LONG) or lead the reference's trie walk into HuffmanEmpty at some depth d
         // (HuffmanTree.hs:78-80): the first d whose d-bit prefix lies at or past the end of all codes.
-        // covered_p: number of P-bit prefixes covered by codes of length <= P (they are [0, covered_p))
-        (void)maxlen;
-        const uint32_t covered_p = first[P] + count[P];
         if (covered_p < (1u << P)) {
-            for (uint32_t idx = lane; idx < (1u << P); idx += PZG_WAVE) {
-                uint32_t c_p = bitrev32(idx) >> (32u - P);  // MSB-first value of the P stream bits
-                if (c_p < covered_p) continue;
+            for (uint32_t i0 = 0; i0 < (1u << P); i0 += PZG_WAVE) {
+                const uint32_t idx = i0 + lane;
+                const uint32_t c_p = bitrev32(idx) >> (32u - P);  // MSB-first value of the P stream bits
                 uint32_t ent;
                 if (e15 == 0u) {
                     ent = mk_entry(1, 0, K_EMPTY_TREE, 0);
                 } else if ((c_p << (15u - P)) < e15) {
                     ent = mk_entry(0, 0, K_LONG, 0);
                 } else {
-                    uint32_t d = 1;
-                    while (d < (uint32_t)P && (((c_p >> ((uint32_t)P - d)) << (15u - d)) < e15)) d++;
+                    uint32_t d = (uint32_t)P;  // smallest d whose d-bit prefix is at or past the end of all codes
+#pragma unroll
+                    for (uint32_t t = (uint32_t)P - 1u; t >= 1u; --t)
+                        if (((c_p >> ((uint32_t)P - t)) << (15u - t)) >= e15) d = t;
                     ent = mk_entry(d, 0, K_EMPTY_BRANCH, 0);
                 }
-                lut[idx] = ent;
+                if (idx < (1u << P) && c_p >= covered_p) lut[idx] = ent;
             }
         }
         wave_sync();
         // pass 2: canonical code of every symbol (step3, Deflate.hs:280-288): first[len] + rank among
-        // the symbols of equal length below it; then the replicated LUT fill.
-        uint32_t basec[16];
-#pragma unroll
-        for (uint32_t l = 0; l < 16u; ++l) basec[l] = 0;
+        // the symbols of equal length below it; then the replicated LUT fill.  Ranks come from
+        // ballots over the lengths present in each 64-symbol round, in symbol order.
         for (uint32_t s0 = 0; s0 < n; s0 += PZG_WAVE) {
             const uint32_t s = s0 + lane;
             const uint32_t len = s < n ? lens[s] : 0u;
-            uint32_t rank = 0, fcode = 0, soff = 0;
-#pragma unroll
-            for (uint32_t l = 1; l < 16u; ++l) {
-                if (count[l] == 0u) continue;  // uniform
-                const bool mine = len == l;
+            uint32_t rank = 0;
+            uint64_t remaining = ballot(len != 0u);
+#pragma nounroll
+            while (remaining) {
+                const uint32_t lsel = read_lane(len, ctz64(remaining));
+                const bool mine = len == lsel;
                 const uint64_t m = ballot(mine);
-                if (mine) {
-                    rank = basec[l] + mbcnt(m);
-                    fcode = first[l];
-                    soff = offs[l];
-                }
-                basec[l] += popc64(m);
+                const uint32_t basec = uni(L.cnt[lsel]);
+                if (mine) rank = basec + mbcnt(m);
+                if (lane == 0u) L.cnt[lsel] = basec + popc64(m);
+                remaining &= ~m;
             }
             if (len != 0u) {
-                const uint32_t c = fcode + rank;
-                if (sorted) sorted[soff + rank] = (uint16_t)s;
+                const uint32_t c = (uint32_t)meta->first[len] + rank;
+                if (sorted) sorted[(uint32_t)meta->offs[len] + rank] = (uint16_t)s;
                 if (len <= (uint32_t)P) {
                     uint32_t ent = TREE == TREE_LITLEN ? litlen_entry(s, len)
                                    : TREE == TREE_DIST ? dist_entry(s, len)
@@ -481,10 +549,10 @@ struct Decoder {
     // Second level (codes longer than the primary table): canonical first-code walk, one length
     // per step, equivalent to HuffmanTree.hs:73-83 advanceTree on the same bits.  Returns an entry.
     template <int TREE>
-    PZG_FN uint32_t decode_long(const TreeMeta *meta, const uint16_t *sorted, uint32_t e15)
+    PZG_FN uint32_t decode_long(uint32_t bits, const TreeMeta *meta, const uint16_t *sorted, uint32_t e15)
     {
         uint32_t code = 0;
-        uint32_t bits = (uint32_t)br.buf;
+#pragma nounroll
         for (uint32_t l = 1; l < 16u; ++l) {
             code = (code << 1) | (bits & 1u);
             bits >>= 1;
@@ -499,11 +567,10 @@ struct Decoder {
         return mk_entry(15, 0, K_EMPTY_BRANCH, 0);  // unreachable: e15 <= 2^15 ends every walk by 15
     }
 
-    // Checks a decoded entry against the real bits left, in the reference's order: the walk/extra
-    // bits run out of data (TRUNCATED) before any error that needs a later bit.
-    PZG_FN int check_entry(uint32_t ent, int32_t empty_branch_status)
+    // Checks a non-symbol entry against the real bits left, in the reference's order: the walk
+    // runs out of data (TRUNCATED) before any error that needs a later bit.
+    PZG_FN int check_entry(uint32_t ent)
     {
-        (void)empty_branch_status;
         const uint32_t kind = ent_kind(ent);
         const int64_t av = br.avail();
         if (kind == K_EMPTY_TREE) {
@@ -519,70 +586,245 @@ struct Decoder {
         return ST_OK;
     }
 
-    // ---- Deflate.hs:106-120 runInflate ------------------------------------------------------------
+    // ---- Deflate.hs:106-120 runInflate: one token, every bit checked against the stream end ------
+    // Used near the end of the stream and for whatever window_step() does not handle itself
+    // (end-of-block, codes longer than the primary tables, every error).
+    // Returns ST_OK (token consumed), 1000 (end of block consumed) or an error status.
+    static constexpr int STEP_EOB = 1000;
+    PZG_FN int token_step_checked()
+    {
+        uint32_t bits = br.peek32();
+        uint32_t e = uni(L.lit_lut[bits & ((1u << LIT_BITS) - 1u)]);
+        uint32_t kind = ent_kind(e);
+        if (kind == K_LONG) {
+            e = decode_long<TREE_LITLEN>(bits, &L.lit_meta, L.lit_sorted, lit_e15);
+            kind = ent_kind(e);
+        }
+        if (kind == K_LIT) {
+            const uint32_t n = ent_n(e);
+            if (br.avail() < (int64_t)n) return fail(ST_TRUNCATED, 0, 0);
+            br.drop(n);
+            put_literal(ent_val(e));
+            maybe_flush();
+            return ST_OK;
+        }
+        if (kind == K_BASE) {
+            const uint32_t n = ent_n(e), ex = ent_e(e);
+            if (br.avail() < (int64_t)(n + ex)) return fail(ST_TRUNCATED, 0, 0);
+            const uint32_t len = ent_val(e) + ((bits >> n) & ((1u << ex) - 1u));
+            br.drop(n + ex);
+            bits = br.peek32();
+            uint32_t d = uni(L.dist_lut[bits & ((1u << DIST_BITS) - 1u)]);
+            uint32_t dk = ent_kind(d);
+            if (dk == K_LONG) {
+                d = decode_long<TREE_DIST>(bits, &L.dist_meta, L.dist_sorted, dist_e15);
+                dk = ent_kind(d);
+            }
+            if (dk != K_BASE) {
+                if (int st = check_entry(d)) return st;
+                // K_BADSYM: distanceArray ! c out of range, the reference throws (Deflate.hs:199-205)
+                return fail(ST_BAD_DIST_SYMBOL, ent_val(d), 0);
+            }
+            const uint32_t dn = ent_n(d), dex = ent_e(d);
+            if (br.avail() < (int64_t)(dn + dex)) return fail(ST_TRUNCATED, 0, 0);
+            const uint32_t dist = ent_val(d) + ((bits >> dn) & ((1u << dex) - 1u));
+            br.drop(dn + dex);
+            if ((uint64_t)dist > op) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
+            copy_match(dist, len);
+            maybe_flush();
+            return ST_OK;
+        }
+        if (int st = check_entry(e)) return st;
+        if (kind == K_EOB) {
+            br.drop(ent_n(e));
+            return STEP_EOB;
+        }
+        // K_BADSYM: lengthArray ! c out of range, the reference throws (Deflate.hs:160-166)
+        return fail(ST_BAD_LITLEN_SYMBOL, ent_val(e), 0);
+    }
+
+    // ---- Deflate.hs:106-120 runInflate, wave-parallel ---------------------------------------------
+    // Precondition: at least WINDOW_MIN_BITS real bits follow the cursor, so every token that
+    // starts within the next 64 bits (at most 48 bits long) lies inside the stream.
+    // Lane k decodes the token that would start k bits ahead: literal/length lookup, length extra
+    // bits, distance lookup at its own offset, distance extra bits.  The scalar walk then visits
+    // the offsets that really are token starts.  Returns ST_OK after consuming >= 1 token or
+    // stopping in front of a token it leaves to token_step_checked(); an error status otherwise.
+    PZG_FN int window_step()
+    {
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        const uint64_t tw0 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- phase A (all lanes): lane k decodes the token that would start k bits ahead ----------
+        const uint32_t i0 = (uint32_t)(br.pos >> 5), boff = (uint32_t)br.pos & 31u;
+        const uint32_t B0 = br.dword(i0), B1 = br.dword(i0 + 1u), B2 = br.dword(i0 + 2u), B3 = br.dword(i0 + 3u),
+                       B4 = br.dword(i0 + 4u);
+        constexpr uint32_t LIT_FLAG = 0x80000000u, F_OTHER = 1u << 24, F_LIT = 1u << 25;
+        LaneVec<uint32_t> INFO;  // [7:0] token bits (64 for a token the walk must stop at)  [16:8] output bytes  [24] other  [25] literal
+        LaneVec<uint32_t> PV;    // literal: LIT_FLAG | byte    match: distance
+        PZG_LANES_BEGIN(k)
+            const uint32_t q = boff + k, sel = q >> 5, r = q & 31u;
+            const uint32_t lo = sel == 0u ? B0 : sel == 1u ? B1 : B2;
+            const uint32_t mid = sel == 0u ? B1 : sel == 1u ? B2 : B3;
+            const uint32_t hi = sel == 0u ? B2 : sel == 1u ? B3 : B4;
+            const uint32_t w_lo = funnel(mid, lo, r), w_hi = funnel(hi, mid, r);  // stream bits [k, k+64)
+            const uint32_t e = L.lit_lut[w_lo & ((1u << LIT_BITS) - 1u)];
+            const uint32_t n = ent_n(e), ex = ent_e(e), kind = ent_kind(e);
+            const uint32_t o = n + ex;                                             // <= 20
+            const uint32_t lenv = ent_val(e) + ((w_lo >> n) & ((1u << ex) - 1u));  // literal byte when kind == K_LIT
+            const uint32_t w2 = funnel(w_hi, w_lo, o);                             // bits after the length code
+            const uint32_t d = L.dist_lut[w2 & ((1u << DIST_BITS) - 1u)];
+            const uint32_t dn = ent_n(d), dex = ent_e(d);                          // dn + dex <= 28
+            const uint32_t dist = ent_val(d) + ((w2 >> dn) & ((1u << dex) - 1u));
+            const bool is_lit = kind == K_LIT;
+            const bool is_match = kind == K_BASE && ent_kind(d) == K_BASE;
+            const uint32_t tb = is_lit ? n : is_match ? o + dn + dex : 64u;
+            const uint32_t lout = is_lit ? 1u : is_match ? lenv : 0u;
+            PZG_LV(INFO, k) = tb | (lout << 8) | (is_lit ? F_LIT : is_match ? 0u : F_OTHER);
+            PZG_LV(PV, k) = is_lit ? (LIT_FLAG | (lenv & 0xffu)) : is_match ? dist : 0u;
+        PZG_LANES_END
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        prof[6] += 1;
+        __builtin_amdgcn_s_waitcnt(0);
+        prof[8] += __builtin_amdgcn_s_memtime() - tw0;
+        const uint64_t tw1 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- phase B (scalar): follow the real chain; S = offsets that are token starts ---------------
+        // The only serial part: one v_readlane and four SALU ops per token, no LDS, no lane work.
+        uint64_t S = 0;
+        uint32_t kend = 0;
+        do {
+            S |= 1ull << kend;
+            kend += lane_get(INFO, kend) & 0xffu;
+        } while (kend < 64u);
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        prof[7] += popc64(S);
+        prof[9] += __builtin_amdgcn_s_memtime() - tw1;
+        const uint64_t te0 = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- phase C (all lanes): place and produce the bytes of all those tokens at once -------------
+        // A segment is at most 64 output bytes.  Token lanes learn their output offset from a prefix
+        // sum of their lengths, drop their lane id into a marker at that offset, and a prefix maximum
+        // tells every output lane which token it belongs to; one ring gather + one ring store follow.
+        // A token ends the segment (and is retried as the head of the next one) if it is not a plain
+        // literal/match, does not fit the 64 lanes, or is a match whose source is not complete before
+        // the segment starts (dist < offset + len) or lies before the output (dist > produced + offset).
+        uint64_t Srem = S;
+        uint32_t consumed = kend;
+        int rc = ST_OK;
+        while (Srem != 0) {
+            const uint32_t hist = op > 0x100000u ? 0x100000u : (uint32_t)op;  // dist <= 32768: a clamp is enough
+            const uint32_t op32 = (uint32_t)op;
+            LaneVec<uint32_t> INCL, STOP;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(INCL, k) = ((Srem >> k) & 1ull) ? ((PZG_LV(INFO, k) >> 8) & 511u) : 0u;
+            PZG_LANES_END
+            lanes_iscan_add(INCL);
+            PZG_LANES_BEGIN(k)
+                const uint32_t inf = PZG_LV(INFO, k), lout = (inf >> 8) & 511u, pv = PZG_LV(PV, k);
+                const uint32_t endb = PZG_LV(INCL, k), start = endb - (((Srem >> k) & 1ull) ? lout : 0u);
+                const bool is_match = (inf & (F_OTHER | F_LIT)) == 0u;
+                const bool bad = (inf & F_OTHER) != 0u || endb > 64u || (is_match && (pv < endb || pv > hist + start));
+                PZG_LV(STOP, k) = (((Srem >> k) & 1ull) && bad) ? 1u : 0u;
+            PZG_LANES_END
+            const uint64_t stopmask = lanes_ballot(STOP);
+            const uint32_t v = stopmask ? ctz64(stopmask) : 64u;
+            const uint32_t vinf = lane_get(INFO, v & 63u);
+            // bytes of the tokens below v
+            const uint32_t run = v < 64u ? lane_get(INCL, v) - ((vinf >> 8) & 511u) : lane_get(INCL, 63u);
+            if (run != 0u) {
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+                prof[13] += 1;
+#endif
+                const uint64_t emit = Srem & (v < 64u ? ((1ull << v) - 1ull) : ~0ull);
+                LaneVec<uint32_t> TOK, PJ;
+                PZG_LANES_BEGIN(k)
+                    const uint32_t lout = (PZG_LV(INFO, k) >> 8) & 511u;
+                    sel_store(((emit >> k) & 1ull) != 0, &L.mk[(PZG_LV(INCL, k) - lout) & 63u], (uint8_t)(k + 1u), k);
+                PZG_LANES_END
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(TOK, j) = L.mk[j];
+                PZG_LANES_END
+                PZG_LANES_BEGIN(j)
+                    L.mk[j] = 0;  // leave the marker clean for the next segment
+                PZG_LANES_END
+                lanes_iscan_max(TOK);
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(TOK, j) = (PZG_LV(TOK, j) - 1u) & 63u;
+                PZG_LANES_END
+                lanes_gather(PJ, PV, TOK);
+                PZG_LANES_BEGIN(j)
+                    const uint32_t pj = PZG_LV(PJ, j);
+                    const uint8_t g = L.ring[(op32 + j - pj) & RMASK];
+                    const uint8_t bv = (pj & LIT_FLAG) ? (uint8_t)pj : g;
+                    sel_store(j < run, &L.ring[(op32 + j) & RMASK], bv, j);
+                PZG_LANES_END
+                op += run;
+                maybe_flush();
+            }
+            if (v >= 64u) break;  // every token of the window is out
+            // token at offset v ended the segment
+            if (vinf & F_OTHER) {
+                consumed = v;  // end of block, long code or error: the checked path takes it from here
+                break;
+            }
+            Srem &= ~((1ull << v) - 1ull);
+            if ((vinf & F_LIT) == 0u) {
+                const uint32_t dist = lane_get(PV, v);
+                if ((uint64_t)dist > op) {  // (`run` bytes were just added to op)
+                    rc = fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
+                    consumed = v;
+                    break;
+                }
+                if (run == 0u) {  // heads the segment and still does not fit: overlapping or longer than a wave
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+                    prof[14] += 1;
+#endif
+                    copy_match(dist, (vinf >> 8) & 511u);
+                    maybe_flush();
+                    Srem &= ~(1ull << v);
+                }
+            }
+        }
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        __builtin_amdgcn_s_waitcnt(0);
+        prof[12] += __builtin_amdgcn_s_memtime() - te0;
+        const uint64_t tw2 = __builtin_amdgcn_s_memtime();
+#endif
+        br.drop(consumed);
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        prof[11] += __builtin_amdgcn_s_memtime() - tw2;
+#endif
+        return rc;
+    }
+
     PZG_FN int token_loop()
     {
         for (;;) {
-            br.refill();
-            uint32_t e = uni(L.lit_lut[br.peek(LIT_BITS)]);
-            uint32_t kind = ent_kind(e);
-            if (kind == K_LONG) {
-                e = decode_long<TREE_LITLEN>(&L.lit_meta, L.lit_sorted, lit_e15);
-                kind = ent_kind(e);
+            pin_uniform();
+            if (br.avail() >= WINDOW_MIN_BITS) {
+                const uint64_t before = br.pos;
+                PZG_T0(tw);
+                const int stw = window_step();
+                PZG_ACC(4, tw);
+                if (stw) return stw;
+                if (br.pos != before) continue;  // else: the very next token needs the checked path
             }
-            const bool tail = br.pos_rel() + 64u > br.end_rel;  // padding bits may be in the buffer
-            if (kind == K_LIT) {
-                const uint32_t n = ent_n(e);
-                if (tail && br.avail() < (int64_t)n) return fail(ST_TRUNCATED, 0, 0);
-                br.drop(n);
-                put_literal(ent_val(e));
-                maybe_flush();
-                continue;
-            }
-            if (kind == K_BASE) {
-                const uint32_t n = ent_n(e), ex = ent_e(e);
-                if (tail && br.avail() < (int64_t)(n + ex)) return fail(ST_TRUNCATED, 0, 0);
-                const uint32_t len = ent_val(e) + (((uint32_t)(br.buf >> n)) & ((1u << ex) - 1u));
-                br.drop(n + ex);
-                br.refill();
-                uint32_t d = uni(L.dist_lut[br.peek(DIST_BITS)]);
-                uint32_t dk = ent_kind(d);
-                if (dk == K_LONG) {
-                    d = decode_long<TREE_DIST>(&L.dist_meta, L.dist_sorted, dist_e15);
-                    dk = ent_kind(d);
-                }
-                if (dk != K_BASE) {
-                    if (int st = check_entry(d, 0)) return st;
-                    // K_BADSYM: distanceArray ! c out of range, the reference throws (Deflate.hs:199-205)
-                    return fail(ST_BAD_DIST_SYMBOL, ent_val(d), 0);
-                }
-                const uint32_t dn = ent_n(d), dex = ent_e(d);
-                if (tail && br.avail() < (int64_t)(dn + dex)) return fail(ST_TRUNCATED, 0, 0);
-                const uint32_t dist = ent_val(d) + (((uint32_t)(br.buf >> dn)) & ((1u << dex) - 1u));
-                br.drop(dn + dex);
-                if ((uint64_t)dist > op) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
-                copy_match(dist, len);
-                maybe_flush();
-                continue;
-            }
-            if (int st = check_entry(e, 0)) return st;
-            if (kind == K_EOB) {
-                br.drop(ent_n(e));
-                return ST_OK;
-            }
-            // K_BADSYM: lengthArray ! c out of range, the reference throws (Deflate.hs:160-166)
-            return fail(ST_BAD_LITLEN_SYMBOL, ent_val(e), 0);
+            PZG_T0(tc);
+            const int st = token_step_checked();
+            PZG_ACC(5, tc);
+            if (st == STEP_EOB) return ST_OK;
+            if (st != ST_OK) return st;
         }
     }
 
     // ---- Deflate.hs:70-78: stored block -------------------------------------------------------------
     PZG_FN int stored_block()
     {
-        br.drop(br.cnt & 7u);  // advanceToByte (Monad.hs:304-307); buf always ends on a byte boundary
-        br.refill();
+        br.align_to_byte();  // advanceToByte (Monad.hs:304-307)
         if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
-        const uint32_t len = br.peek(16);
-        const uint32_t nlen = (uint32_t)(br.buf >> 16) & 0xffffu;
+        const uint32_t w = br.peek32();
+        const uint32_t len = w & 0xffffu, nlen = w >> 16;
         if (len != ((~nlen) & 0xffffu)) return fail(ST_FMT_LEN_NLEN, len, nlen);
         br.drop(32);
         const uint64_t p = stream_bit_pos() >> 3;  // byte offset of the raw data in the stream
@@ -594,8 +836,11 @@ struct Decoder {
         while (done < len) {
             uint32_t piece = len - done < PIECE ? len - done : PIECE;
             if (op + piece - flushed > RING) flush_to(op & ~(uint64_t)15u);
-            for (uint32_t k = lane; k < piece; k += PZG_WAVE)
-                L.ring[((uint32_t)op + k) & RMASK] = in[p + done + k];
+            for (uint32_t k0 = 0; k0 < piece; k0 += PZG_WAVE) {
+                const uint32_t k = k0 + lane;
+                const uint8_t v = in[p + done + (k < piece ? k : piece - 1u)];
+                sel_store(k < piece, &L.ring[((uint32_t)op + k) & RMASK], v, lane);
+            }
             op += piece;
             done += piece;
         }
@@ -610,9 +855,10 @@ struct Decoder {
     {
         if (fixed_loaded) return;
         const uint32_t lane = lane_id();
-        for (uint32_t s = lane; s < 288u; s += PZG_WAVE)
-            L.lens[s] = (uint8_t)(s <= 143u ? 8u : s <= 255u ? 9u : s <= 279u ? 7u : 8u);
-        for (uint32_t s = lane; s < 32u; s += PZG_WAVE) L.lens[288u + s] = 5u;
+        for (uint32_t s0 = 0; s0 < 320u; s0 += PZG_WAVE) {
+            const uint32_t s = s0 + lane;
+            if (s < 320u) L.lens[s] = (uint8_t)(s <= 143u ? 8u : s <= 255u ? 9u : s <= 279u ? 7u : s <= 287u ? 8u : 5u);
+        }
         build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, L.lit_sorted, &L.lit_meta, &lit_e15);
         build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, L.dist_sorted, &L.dist_meta, &dist_e15);
         fixed_loaded = 1;
@@ -622,43 +868,48 @@ struct Decoder {
     PZG_FN int dynamic_header(uint32_t block_bit)
     {
         const uint32_t lane = lane_id();
-        br.refill();
         if (br.avail() < 14) return fail(ST_TRUNCATED, 0, 0);
-        const uint32_t hlit = 257u + br.peek(5);
-        const uint32_t hdist = 1u + ((uint32_t)(br.buf >> 5) & 31u);
-        const uint32_t hclen = 4u + ((uint32_t)(br.buf >> 10) & 15u);
+        uint32_t w = br.peek32();
+        const uint32_t hlit = 257u + (w & 31u);
+        const uint32_t hdist = 1u + ((w >> 5) & 31u);
+        const uint32_t hclen = 4u + ((w >> 10) & 15u);
         br.drop(14);
         // hclen x 3-bit lengths in codeLengthOrder (Deflate.hs:87-88,290-292)
-        for (uint32_t i = lane; i < 20u; i += PZG_WAVE) L.cl_lens[i] = 0;
+        for (uint32_t i0 = 0; i0 < 20u; i0 += PZG_WAVE) sel_store(i0 + lane < 20u, &L.cl_lens[(i0 + lane) % 20u], 0, lane);
         wave_sync();
-        for (uint32_t i = 0; i < hclen; ++i) {
-            br.refill();
-            if (br.avail() < 3) return fail(ST_TRUNCATED, 0, 0);
-            const uint32_t v = br.peek(3);
-            br.drop(3);
-            // codeLengthOrder = 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15 packed 5 bits each
-            const uint64_t ORD_LO = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 |
-                                    9ull << 30 | 6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
-            const uint64_t ORD_HI = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
-            const uint32_t sym = i < 12u ? (uint32_t)(ORD_LO >> (5u * i)) & 31u : (uint32_t)(ORD_HI >> (5u * (i - 12u))) & 31u;
-            if (lane == 0u) L.cl_lens[sym] = (uint8_t)v;
+        if (br.avail() < (int64_t)(3u * hclen)) return fail(ST_TRUNCATED, 0, 0);
+        // codeLengthOrder = 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15 packed 5 bits each
+        const uint64_t ORD_LO = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 |
+                                6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+        const uint64_t ORD_HI = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+        for (uint32_t i0 = 0; i0 < hclen; i0 += 10u) {  // up to 10 fields (30 bits) per peek
+            w = br.peek32();
+            const uint32_t m = hclen - i0 < 10u ? hclen - i0 : 10u;
+            for (uint32_t j0 = 0; j0 < m; j0 += PZG_WAVE) {
+                const uint32_t j = j0 + lane;
+                const uint32_t i = i0 + j;
+                const uint32_t sym = i < 12u ? (uint32_t)(ORD_LO >> (5u * (i % 12u))) & 31u
+                                             : (uint32_t)(ORD_HI >> (5u * ((i - 12u) % 7u))) & 31u;
+                sel_store(j < m, &L.cl_lens[sym % 20u], (uint8_t)((w >> (3u * (j % 10u))) & 7u), lane);
+            }
+            br.drop(3u * m);
         }
         uint32_t cl_e15;
-        if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, nullptr, nullptr, &cl_e15))
+        if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, nullptr, &L.cl_meta, &cl_e15))
             return fail(ST_HUFF_BUILD, TREE_CODELEN, block_bit);
         // getCodeLengths (Deflate.hs:124-156) over HLIT+HDIST as ONE sequence
         const uint32_t maxl = hlit + hdist;
         uint32_t n = 0, prev = 0;
         while (n < maxl) {
-            br.refill();
-            const uint32_t e = uni(L.dist_lut[br.peek(CL_BITS)]);
-            if (int st = check_entry(e, 0)) return st;
+            w = br.peek32();
+            const uint32_t e = uni(L.dist_lut[w & ((1u << CL_BITS) - 1u)]);
+            if (int st = check_entry(e)) return st;
             const uint32_t sym = ent_val(e), cn = ent_n(e), ce = ent_e(e);
             if (br.avail() < (int64_t)(cn + ce)) return fail(ST_TRUNCATED, 0, 0);
-            const uint32_t extra = ((uint32_t)(br.buf >> cn)) & ((1u << ce) - 1u);
+            const uint32_t extra = (w >> cn) & ((1u << ce) - 1u);
             br.drop(cn + ce);
             if (sym <= 15u) {
-                if (lane == 0u) L.lens[n] = (uint8_t)sym;
+                sel_store(lane == 0u, &L.lens[n], (uint8_t)sym, lane);
                 n++;
                 prev = sym;
                 continue;
@@ -677,7 +928,8 @@ struct Decoder {
                 prev = 0;
             }
             // repeats that run past HLIT+HDIST are accepted and spill into extra distance symbols (Deflate.hs:132,96-97)
-            for (uint32_t k = lane; k < num; k += PZG_WAVE) L.lens[n + k] = (uint8_t)val;
+            for (uint32_t k0 = 0; k0 < num; k0 += PZG_WAVE)
+                sel_store(k0 + lane < num, &L.lens[n + k0 + lane], (uint8_t)val, lane);
             n += num;
         }
         wave_sync();
@@ -706,8 +958,12 @@ struct Decoder {
         status = ST_OK;
         detail0 = detail1 = 0;
         in_byte0 = 0;
+        for (uint32_t i0 = 0; i0 < 64u; i0 += PZG_WAVE) L.mk[(i0 + lane_id()) & 63u] = 0;
+        wave_sync();
         br.start(in, in_len, 0);
+        PZG_T0(tall);
         decode();
+        PZG_ACC(0, tall);
         uint64_t used_bits = stream_bit_pos();
         uint64_t used = (used_bits + 7u) >> 3;
         if (used > in_len) used = in_len;
@@ -724,45 +980,49 @@ struct Decoder {
     {
         // Zlib.hs:55-67: CMF, FLG; FCHECK, then CM, then CINFO
         if (br.avail() < 16) return fail(ST_TRUNCATED, 0, 0);
-        const uint32_t cmf = br.peek(8);
-        const uint32_t flg = (uint32_t)(br.buf >> 8) & 0xffu;
+        const uint32_t hw = br.peek32();
+        const uint32_t cmf = hw & 0xffu, flg = (hw >> 8) & 0xffu;
         br.drop(16);
         if (((cmf << 8) | flg) % 31u != 0u) return fail(ST_HDR_FCHECK, (cmf << 8) | flg, 0);
         if ((cmf & 15u) != 8u) return fail(ST_HDR_METHOD, cmf & 15u, 0);
         if ((cmf >> 4) > 7u) return fail(ST_HDR_WINDOW, cmf >> 4, 0);
         if (flg & 0x20u) {  // Zlib.hs:68: skip DICTID, carry on with an empty history
-            br.refill();
             if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
             br.drop(32);
         }
         for (;;) {  // Deflate.hs:45-50 go
-            br.refill();
+            pin_uniform();
             const uint32_t block_bit = (uint32_t)stream_bit_pos();
             if (br.avail() < 3) return fail(ST_TRUNCATED, 0, 0);
-            const uint32_t bfinal = br.peek(1);
-            const uint32_t btype = (uint32_t)(br.buf >> 1) & 3u;
+            const uint32_t bh = br.peek32();
+            const uint32_t bfinal = bh & 1u, btype = (bh >> 1) & 3u;
             br.drop(3);
             int st;
             if (btype == 0u) {
                 st = stored_block();
-            } else if (btype == 1u) {
-                load_fixed_tables();
-                st = token_loop();
-            } else if (btype == 2u) {
-                st = dynamic_header(block_bit);
-                if (st == ST_OK) st = token_loop();
-            } else {
+            } else if (btype == 3u) {
                 st = fail(ST_FMT_BTYPE, 3, 0);
+            } else {
+                PZG_T0(th);
+                if (btype == 1u) {
+                    load_fixed_tables();
+                    st = ST_OK;
+                } else {
+                    st = dynamic_header(block_bit);
+                }
+                PZG_ACC(1, th);
+                PZG_T0(tt);
+                if (st == ST_OK) st = token_loop();
+                PZG_ACC(2, tt);
             }
             if (st != ST_OK) return st;
             if (bfinal) break;
         }
         // Deflate.hs:52-63 checkChecksum: align, fold the rest of the window, compare big-endian
         flush_to(op);
-        br.drop(br.cnt & 7u);
-        br.refill();
+        br.align_to_byte();
         if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
-        const uint32_t t = (uint32_t)br.buf;
+        const uint32_t t = br.peek32();
         const uint32_t theirs = (t << 24) | ((t & 0xff00u) << 8) | ((t >> 8) & 0xff00u) | (t >> 24);
         br.drop(32);
         const uint32_t ours = (adler_b << 16) | adler_a;

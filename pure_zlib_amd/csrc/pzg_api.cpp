@@ -36,6 +36,7 @@ struct pzg_ctx {
     void *h_stage = nullptr;  // pinned host staging for the host-pointer path
     size_t h_stage_cap = 0;
     std::string last_error;
+    void *prof_buf = nullptr;  // diagnostic builds only
 };
 
 namespace {
@@ -83,6 +84,16 @@ int launch_timed(pzg_ctx *ctx, const pzg::InflateArgs &args)
 }  // namespace
 
 extern "C" {
+
+#if defined(PZG_PROFILE)
+// diagnostic builds only: device buffer of 12 uint64 per stream the kernel fills with cycle counters
+int pzg_prof_buffer(pzg_ctx *ctx, uint32_t n, uint64_t *host_out)
+{
+    if (!ctx->prof_buf) { if (hipMalloc(&ctx->prof_buf, 128u * 1048576u) != hipSuccess) return -1; }
+    if (host_out) return hipMemcpy(host_out, ctx->prof_buf, 128u * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return 0;
+}
+#endif
 
 int pzg_init(int device, pzg_ctx **out)
 {
@@ -159,7 +170,10 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     if (flags & PZG_DEVICE_PTRS) {
         if (!out_base) return PZG_RC_BAD_ARG;
         pzg::InflateArgs a{in_base, in_off, in_len, out_base, out_off, out_cap, out_len,
-                           status,  detail, in_used, adler,   nullptr, n};
+                           status,  detail, in_used, adler,   nullptr, nullptr, n};
+#if defined(PZG_PROFILE)
+        a.prof_out = (uint64_t *)ctx->prof_buf;
+#endif
         int rc = launch_timed(ctx, a);
         if (rc != PZG_RC_OK) return rc;
         if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -210,6 +224,10 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     a.adler = (uint32_t *)(d_meta + m_adler);
     a.detail = (uint32_t *)(d_meta + m_detail);
     a.order = nullptr;
+    a.prof_out = nullptr;
+#if defined(PZG_PROFILE)
+    a.prof_out = (uint64_t *)ctx->prof_buf;
+#endif
     a.n = n;
     if ((rc = launch_timed(ctx, a)) != PZG_RC_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_len, a.out_len, 8 * N, hipMemcpyDeviceToHost, s));

@@ -21,7 +21,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs a)
 {
     __shared__ WaveLds<RING_BITS> lds;
     uint32_t i = blockIdx.x;
+#if !defined(PZG_PROFILE)
     if (a.order) i = a.order[i];
+#endif
     Decoder<RING_BITS> dec(lds);
     StreamResult r;
     dec.run(a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i], &r);
@@ -34,6 +36,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs a)
         }
         if (a.in_used) a.in_used[i] = r.in_used;
         if (a.adler) a.adler[i] = r.adler;
+#if defined(PZG_PROFILE)
+        // diagnostic build: the 12 phase counters of stream i go to prof_out[12*i ..] (passed in place of `order`)
+        if (a.prof_out)
+            for (int q = 0; q < 16; ++q) a.prof_out[16 * (size_t)i + q] = dec.prof[q];
+#endif
     }
 }
 

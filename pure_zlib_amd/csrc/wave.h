@@ -148,6 +148,126 @@ PZG_FN uint32_t dot4(uint32_t x, uint32_t w, uint32_t c)
 #endif
 }
 
+// ---- per-lane values -------------------------------------------------------------------------
+// Code between PZG_LANES_BEGIN(k) and PZG_LANES_END runs once per lane k of a 64-lane wave: on the
+// device it is the ordinary SIMT body (k = lane id, a LaneVec is one VGPR); in the one-thread host
+// model it is an explicit loop over 64 lanes and a LaneVec is a 64-entry array.  Only code that
+// does not communicate between lanes inside the block may be written this way.
+#if PZG_DEVICE_PASS
+template <class T>
+struct LaneVec {
+    T v;
+};
+#define PZG_LANES_BEGIN(k) { const uint32_t k = ::pzg::lane_id();
+#define PZG_LANES_END }
+#define PZG_LV(x, k) ((x).v)
+#else
+template <class T>
+struct LaneVec {
+    T v[64];
+};
+#define PZG_LANES_BEGIN(k) for (uint32_t k = 0; k < 64u; ++k) {
+#define PZG_LANES_END }
+#define PZG_LV(x, k) ((x).v[k])
+#endif
+
+// value of lane `l` (wave-uniform l) of a LaneVec
+PZG_FN uint32_t lane_get(const LaneVec<uint32_t> &x, uint32_t l)
+{
+#if PZG_DEVICE_PASS
+    return (uint32_t)__builtin_amdgcn_readlane((int)x.v, (int)l);
+#else
+    return x.v[l & 63u];
+#endif
+}
+
+// number of set bits of m below lane k
+PZG_FN uint32_t mbcnt_k(uint64_t m, uint32_t k)
+{
+#if PZG_DEVICE_PASS
+    (void)k;
+    return mbcnt(m);
+#else
+    return (uint32_t)__builtin_popcountll(m & ((1ull << k) - 1ull));
+#endif
+}
+
+// (hi:lo) >> r, r in [0,32): v_alignbit_b32
+PZG_FN uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t r)
+{
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (r & 31u));
+}
+
+// ---- cross-lane operations on whole LaneVecs (64 lanes) ----------------------------------------
+#if PZG_DEVICE_PASS
+// DPP controls (gfx9/CDNA): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+#endif
+
+// inclusive prefix sum across the 64 lanes
+PZG_FN void lanes_iscan_add(LaneVec<uint32_t> &x)
+{
+#if PZG_DEVICE_PASS
+    uint32_t v = x.v;
+    v += dpp_zero<0x111, 0xf>(v);
+    v += dpp_zero<0x112, 0xf>(v);
+    v += dpp_zero<0x114, 0xf>(v);
+    v += dpp_zero<0x118, 0xf>(v);
+    v += dpp_zero<0x142, 0xa>(v);  // lane 15 of rows 0,2 into rows 1,3
+    v += dpp_zero<0x143, 0xc>(v);  // lane 31 into rows 2,3
+    x.v = v;
+#else
+    for (uint32_t k = 1; k < 64u; ++k) x.v[k] += x.v[k - 1];
+#endif
+}
+
+// inclusive prefix maximum across the 64 lanes (values are small non-negative integers)
+PZG_FN void lanes_iscan_max(LaneVec<uint32_t> &x)
+{
+#if PZG_DEVICE_PASS
+    uint32_t v = x.v, t;
+    t = dpp_zero<0x111, 0xf>(v); v = v > t ? v : t;
+    t = dpp_zero<0x112, 0xf>(v); v = v > t ? v : t;
+    t = dpp_zero<0x114, 0xf>(v); v = v > t ? v : t;
+    t = dpp_zero<0x118, 0xf>(v); v = v > t ? v : t;
+    t = dpp_zero<0x142, 0xa>(v); v = v > t ? v : t;
+    t = dpp_zero<0x143, 0xc>(v); v = v > t ? v : t;
+    x.v = v;
+#else
+    for (uint32_t k = 1; k < 64u; ++k) x.v[k] = x.v[k] > x.v[k - 1] ? x.v[k] : x.v[k - 1];
+#endif
+}
+
+// out[k] = src[idx[k] & 63]  (ds_bpermute_b32: a gather through the LDS crossbar, no LDS memory)
+PZG_FN void lanes_gather(LaneVec<uint32_t> &out, const LaneVec<uint32_t> &src, const LaneVec<uint32_t> &idx)
+{
+#if PZG_DEVICE_PASS
+    out.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx.v << 2), (int)src.v);
+#else
+    LaneVec<uint32_t> tmp;
+    for (uint32_t k = 0; k < 64u; ++k) tmp.v[k] = src.v[idx.v[k] & 63u];
+    out = tmp;
+#endif
+}
+
+// mask of lanes whose predicate is set (the LaneVec holds 0/1)
+PZG_FN uint64_t lanes_ballot(const LaneVec<uint32_t> &p)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_ballot_w64(p.v != 0u);
+#else
+    uint64_t m = 0;
+    for (uint32_t k = 0; k < 64u; ++k) m |= (uint64_t)(p.v[k] != 0u) << k;
+    return m;
+#endif
+}
+
+PZG_FN uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+
 PZG_FN uint32_t bitrev32(uint32_t x)
 {
 #if defined(__clang__)

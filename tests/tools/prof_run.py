@@ -1,0 +1,42 @@
+"""Diagnostic: run a small batch through build/prof/libpzg.so (PZG_PROFILE build) and print the
+per-phase s_memtime cycle breakdown.  Not a test, not shipped."""
+import sys, os, zlib, ctypes as C
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import corpus
+from pure_zlib_amd import _ffi
+_ffi.LIB_PATH = os.path.join(ROOT, "build", "prof", "libpzg.so")
+import pure_zlib_amd as P
+ctx = P.Context(0)
+L = _ffi.lib()
+L.pzg_prof_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+nstreams = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+datas = [corpus.zipf_text(size, i % 64) for i in range(64)]
+zs = [zlib.compress(d, 6) for d in datas]
+streams = [zs[i % 64] for i in range(nstreams)]
+in_off = np.zeros(nstreams, np.uint64); out_off = np.zeros(nstreams, np.uint64)
+ip = op = 0
+for k, s in enumerate(streams):
+    in_off[k] = ip; out_off[k] = op; ip += (len(s) + 255) // 256 * 256; op += (size + 255) // 256 * 256
+in_buf = np.zeros(ip + 16, np.uint8)
+for k, s in enumerate(streams):
+    in_buf[int(in_off[k]):int(in_off[k]) + len(s)] = np.frombuffer(s, np.uint8)
+out_buf = np.zeros(op + 16, np.uint8)
+in_len = np.array([len(s) for s in streams], np.uint64); cap = np.full(nstreams, size, np.uint64)
+L.pzg_prof_buffer(ctx.handle, nstreams, None)
+for rep in range(2):
+    out_len, status, detail, in_used, adler = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, cap)
+ms = ctx.last_kernel_ms()
+prof = np.zeros((nstreams, 16), np.uint64)
+L.pzg_prof_buffer(ctx.handle, nstreams, prof.ctypes.data)
+m = prof.astype(np.float64).mean(axis=0)
+print(f"streams {nstreams} x {size} B; kernel {ms:.3f} ms; status ok {int((status==0).sum())}; outputs ok {all(out_buf[int(out_off[k]):int(out_off[k])+size].tobytes()==datas[k%64] for k in range(min(nstreams,64)))}")
+names = ["total", "header+tables", "token loop", "flush+adler", "window_step", "checked steps", "#windows", "#tokens in windows",
+         "  win: lookups", "  win: walk+emit", "#matches", "  win: drop/slide", "  win: emission", "#segments", "#general copies", "-"]
+for i, nme in enumerate(names):
+    extra = f"({100*m[i]/m[0]:5.1f}%)" if not nme.startswith("#") else ""
+    print(f"  {nme:22s} {m[i]:12.0f} {extra}")
+print(f"  emission cycles/segment {m[12]/max(m[13],1):.0f}; gather cycles/token {(m[9]-m[12])/max(m[7],1):.0f}")
+print(f"  cycles/window {m[4]/max(m[6],1):.0f}; tokens/window {m[7]/max(m[6],1):.2f}; cycles/token {m[4]/max(m[7],1):.0f}; lookups/window {m[8]/max(m[6],1):.0f}; walk/window {m[9]/max(m[6],1):.0f}")
