@@ -55,7 +55,8 @@ enum : int32_t {
     ST_BAD_DISTANCE = 11,
     ST_BAD_LITLEN_SYMBOL = 12,
     ST_BAD_DIST_SYMBOL = 13,
-    ST_OUT_TOO_SMALL = 14
+    ST_OUT_TOO_SMALL = 14,
+    ST_RETRY_FULL_RING = 100  // internal: a small-ring launch met an output larger than its capacity; the 32 KiB ring kernel redoes the stream
 };
 
 enum { TREE_CODELEN = 0, TREE_LITLEN = 1, TREE_DIST = 2 };
@@ -314,6 +315,7 @@ struct Decoder {
         const uint32_t lane = lane_id();
         const bool out_al = (((uintptr_t)out) & 15u) == 0u;
         uint32_t a_l = 0, w_l = 0, u_l = 0;
+#pragma nounroll
         for (uint32_t it = 0; it * PZG_WAVE < nvec; ++it) {
             const uint32_t j = it * PZG_WAVE + lane;
             if (j < nvec) {
@@ -371,6 +373,9 @@ struct Decoder {
         adler_a = (uint32_t)(((uint64_t)adler_a + sum_a) % ADLER_MOD);
         adler_b = (uint32_t)(nb % ADLER_MOD);
         flushed = to;
+#if PZG_DEVICE_PASS
+        if (HYBRID) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // far reads may follow: the stores must have landed
+#endif
         wave_sync();
         PZG_ACC(3, tf);
     }
@@ -388,6 +393,27 @@ struct Decoder {
     {
         uint8_t *p = pred ? dst : &L.dump[lane & 63u];
         *p = v;
+    }
+
+    // The byte `back` positions before the output cursor (1 <= back <= 32768, back <= op).
+    // The LDS ring holds the last RING bytes.  With RING_BITS == 15 that is the whole DEFLATE window.
+    // With a smaller ring (more resident stream-waves per CU) older bytes come from the stream's own
+    // output in HBM/L2: everything older than the ring has been flushed (op - flushed <= FLUSH_AT),
+    // flush_to() waits for its stores, and the load bypasses this CU's L1 (nt), so it sees them.
+    static constexpr bool HYBRID = RING_BITS < 15;
+    PZG_FN uint8_t fetch_near(uint32_t back) const { return L.ring[((uint32_t)op - back) & RMASK]; }
+    PZG_FN uint8_t fetch_far(bool is_far, uint32_t back) const
+    {
+        // lanes that are not far (or a count-only stream whose bytes were never stored) read byte 0 of the output
+        uint64_t p = op - back;
+        const bool ok = is_far && p < cap;
+        p = ok ? p : 0u;
+#if PZG_DEVICE_PASS
+        const uint8_t v = cap ? __builtin_nontemporal_load(out + p) : (uint8_t)0;
+#else
+        const uint8_t v = cap ? out[p] : (uint8_t)0;
+#endif
+        return v;
     }
 
     // Monad.hs:309-315 emitByte -> OutputWindow.hs:64-68 addByte
@@ -408,7 +434,11 @@ struct Decoder {
         const uint32_t src0 = (uint32_t)op - dist;
         const uint32_t dst0 = (uint32_t)op;
         if (len <= PZG_WAVE && dist >= len) {  // the common case: one read, one write
-            const uint8_t v = L.ring[(src0 + lane) & RMASK];  // lanes >= len read a harmless ring byte
+            uint8_t v = L.ring[(src0 + lane) & RMASK];  // lanes >= len read a harmless ring byte
+            if (HYBRID) {
+                const bool far = lane < len && dist - lane > RING;
+                if (ballot(far)) v = far ? fetch_far(far, dist - lane) : v;
+            }
             sel_store(lane < len, &L.ring[(dst0 + lane) & RMASK], v, lane);
             op += len;
             return;
@@ -434,6 +464,10 @@ struct Decoder {
 #endif
                 }
                 v[c] = L.ring[(src0 + (k < len ? off : 0u)) & RMASK];
+                if (HYBRID) {  // only a non-overlapping match (off == k) can reach past the ring
+                    const bool far = k < len && dist - off > RING;
+                    if (ballot(far)) v[c] = far ? fetch_far(far, dist - off) : v[c];
+                }
             }
         }
 #pragma unroll
@@ -459,6 +493,7 @@ struct Decoder {
         if (PZG_WAVE == 1u)
             for (uint32_t i = 1; i < 16u; ++i) L.cnt[i] = 0u;
         wave_sync();
+#pragma nounroll
         for (uint32_t s0 = 0; s0 < n; s0 += PZG_WAVE) {  // every loop here has a wave-uniform trip count
             const uint32_t s = s0 + lane;
             const uint32_t len = s < n ? lens[s] : 0u;
@@ -493,6 +528,7 @@ struct Decoder {
         // code (K_LONG) or lead the reference's trie walk into HuffmanEmpty at some depth d
         // (HuffmanTree.hs:78-80): the first d whose d-bit prefix lies at or past the end of all codes.
         if (covered_p < (1u << P)) {
+#pragma nounroll
             for (uint32_t i0 = 0; i0 < (1u << P); i0 += PZG_WAVE) {
                 const uint32_t idx = i0 + lane;
                 const uint32_t c_p = bitrev32(idx) >> (32u - P);  // MSB-first value of the P stream bits
@@ -515,6 +551,7 @@ struct Decoder {
         // pass 2: canonical code of every symbol (step3, Deflate.hs:280-288): first[len] + rank among
         // the symbols of equal length below it; then the replicated LUT fill.  Ranks come from
         // ballots over the lengths present in each 64-symbol round, in symbol order.
+#pragma nounroll
         for (uint32_t s0 = 0; s0 < n; s0 += PZG_WAVE) {
             const uint32_t s = s0 + lane;
             const uint32_t len = s < n ? lens[s] : 0u;
@@ -538,6 +575,7 @@ struct Decoder {
                                    : TREE == TREE_DIST ? dist_entry(s, len)
                                                        : codelen_entry(s, len);
                     const uint32_t rev = bitrev32(c) >> (32u - len);
+#pragma nounroll
                     for (uint32_t idx = rev; idx < (1u << P); idx += (1u << len)) lut[idx] = ent;
                 }
             }
@@ -753,11 +791,28 @@ struct Decoder {
                     PZG_LV(TOK, j) = (PZG_LV(TOK, j) - 1u) & 63u;
                 PZG_LANES_END
                 lanes_gather(PJ, PV, TOK);
+                LaneVec<uint32_t> BV;
                 PZG_LANES_BEGIN(j)
                     const uint32_t pj = PZG_LV(PJ, j);
                     const uint8_t g = L.ring[(op32 + j - pj) & RMASK];
-                    const uint8_t bv = (pj & LIT_FLAG) ? (uint8_t)pj : g;
-                    sel_store(j < run, &L.ring[(op32 + j) & RMASK], bv, j);
+                    PZG_LV(BV, j) = (pj & LIT_FLAG) ? (pj & 0xffu) : g;
+                PZG_LANES_END
+                if (HYBRID) {  // sources older than the ring: the stream's own flushed output
+                    LaneVec<uint32_t> FAR;
+                    PZG_LANES_BEGIN(j)
+                        const uint32_t pj = PZG_LV(PJ, j);
+                        PZG_LV(FAR, j) = (j < run && (pj & LIT_FLAG) == 0u && pj - j > RING) ? 1u : 0u;
+                    PZG_LANES_END
+                    if (lanes_ballot(FAR)) {
+                        PZG_LANES_BEGIN(j)
+                            const bool far = PZG_LV(FAR, j) != 0u;
+                            const uint8_t fv = fetch_far(far, PZG_LV(PJ, j) - j);
+                            PZG_LV(BV, j) = far ? fv : PZG_LV(BV, j);
+                        PZG_LANES_END
+                    }
+                }
+                PZG_LANES_BEGIN(j)
+                    sel_store(j < run, &L.ring[(op32 + j) & RMASK], (uint8_t)PZG_LV(BV, j), j);
                 PZG_LANES_END
                 op += run;
                 maybe_flush();
@@ -836,6 +891,7 @@ struct Decoder {
         while (done < len) {
             uint32_t piece = len - done < PIECE ? len - done : PIECE;
             if (op + piece - flushed > RING) flush_to(op & ~(uint64_t)15u);
+#pragma nounroll
             for (uint32_t k0 = 0; k0 < piece; k0 += PZG_WAVE) {
                 const uint32_t k = k0 + lane;
                 const uint8_t v = in[p + done + (k < piece ? k : piece - 1u)];
@@ -855,6 +911,7 @@ struct Decoder {
     {
         if (fixed_loaded) return;
         const uint32_t lane = lane_id();
+#pragma nounroll
         for (uint32_t s0 = 0; s0 < 320u; s0 += PZG_WAVE) {
             const uint32_t s = s0 + lane;
             if (s < 320u) L.lens[s] = (uint8_t)(s <= 143u ? 8u : s <= 255u ? 9u : s <= 279u ? 7u : s <= 287u ? 8u : 5u);
@@ -882,9 +939,11 @@ struct Decoder {
         const uint64_t ORD_LO = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 |
                                 6ull << 35 | 10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
         const uint64_t ORD_HI = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+#pragma nounroll
         for (uint32_t i0 = 0; i0 < hclen; i0 += 10u) {  // up to 10 fields (30 bits) per peek
             w = br.peek32();
             const uint32_t m = hclen - i0 < 10u ? hclen - i0 : 10u;
+#pragma nounroll
             for (uint32_t j0 = 0; j0 < m; j0 += PZG_WAVE) {
                 const uint32_t j = j0 + lane;
                 const uint32_t i = i0 + j;
@@ -928,6 +987,7 @@ struct Decoder {
                 prev = 0;
             }
             // repeats that run past HLIT+HDIST are accepted and spill into extra distance symbols (Deflate.hs:132,96-97)
+#pragma nounroll
             for (uint32_t k0 = 0; k0 < num; k0 += PZG_WAVE)
                 sel_store(k0 + lane < num, &L.lens[n + k0 + lane], (uint8_t)val, lane);
             n += num;
@@ -967,6 +1027,11 @@ struct Decoder {
         uint64_t used_bits = stream_bit_pos();
         uint64_t used = (used_bits + 7u) >> 3;
         if (used > in_len) used = in_len;
+        if (HYBRID && op > cap && (status == ST_OK || status == ST_CHECKSUM)) {
+            // bytes past the capacity were never stored, so far reads of them (and the checksum) are not
+            // to be trusted: the 32 KiB-ring kernel, which needs nothing but LDS, redoes this stream
+            status = ST_RETRY_FULL_RING;
+        }
         if (status == ST_OK && op > cap) status = ST_OUT_TOO_SMALL;
         res->status = status;
         res->detail0 = detail0;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -37,6 +38,7 @@ struct pzg_ctx {
     size_t h_stage_cap = 0;
     std::string last_error;
     void *prof_buf = nullptr;  // diagnostic builds only
+    void *d_counter = nullptr; // stream-index counter of the persistent inflate waves
 };
 
 namespace {
@@ -72,10 +74,14 @@ int arena_reserve(pzg_ctx *ctx, Arena &a, size_t bytes)
     return PZG_RC_OK;
 }
 
-int launch_timed(pzg_ctx *ctx, const pzg::InflateArgs &args)
+int launch_timed(pzg_ctx *ctx, const pzg::InflateArgs &args_in)
 {
+    pzg::InflateArgs args = args_in;
+    args.counter = (uint32_t *)ctx->d_counter;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(ctx, pzg::launch_inflate(args, 15, ctx->stream));
+    int ring_bits = 15;
+    if (const char *e = getenv("PZG_RING_BITS")) ring_bits = atoi(e);  // experiment knob: caller guarantees outputs fit
+    HIP_TRY(ctx, pzg::launch_inflate(args, ring_bits, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
     return PZG_RC_OK;
@@ -112,6 +118,10 @@ int pzg_init(int device, pzg_ctx **out)
         return PZG_RC_NO_DEVICE;
     }
     ctx->stream = ctx->own_stream;
+    if (hipMalloc(&ctx->d_counter, 256) != hipSuccess) {
+        delete ctx;
+        return PZG_RC_NO_MEMORY;
+    }
     *out = ctx;
     return PZG_RC_OK;
 }
@@ -124,6 +134,7 @@ void pzg_shutdown(pzg_ctx *ctx)
     for (Arena *a : {&ctx->a_in, &ctx->a_out, &ctx->a_meta, &ctx->a_adler})
         if (a->p) (void)hipFree(a->p);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -170,7 +181,7 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     if (flags & PZG_DEVICE_PTRS) {
         if (!out_base) return PZG_RC_BAD_ARG;
         pzg::InflateArgs a{in_base, in_off, in_len, out_base, out_off, out_cap, out_len,
-                           status,  detail, in_used, adler,   nullptr, nullptr, n};
+                           status,  detail, in_used, adler,   nullptr, nullptr, nullptr, n};
 #if defined(PZG_PROFILE)
         a.prof_out = (uint64_t *)ctx->prof_buf;
 #endif

@@ -7,6 +7,7 @@
 // Written for CDNA4 only: wave64, LDS ring per wave, no MFMA (there is no contraction on this path).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "inflate_core.h"
 #include "pzg_launch.h"
@@ -16,42 +17,79 @@ namespace pzg {
 // ------------------------------------------------------------------------------------------------
 // inflate: grid = number of streams, block = 64 threads.  LDS per workgroup = sizeof(WaveLds) =
 // 38.7 KiB at RING_BITS = 15, so four stream-waves are resident per CU (one per SIMD).
-template <int RING_BITS>
-__global__ __launch_bounds__(64) void inflate_kernel(InflateArgs a)
+template <int RING_BITS, bool FIXUP>
+__global__ __launch_bounds__(64, 4) void inflate_kernel(InflateArgs a)
 {
     __shared__ WaveLds<RING_BITS> lds;
-    uint32_t i = blockIdx.x;
+    // Persistent stream-waves: the grid is sized to the residency of the chip and every wave pulls
+    // stream indices from one device-scope counter until the batch is drained (a returning atomic is
+    // ~0.3-1 us, nothing next to a >= 50 us stream; launching one workgroup per stream instead costs
+    // more in dispatch than the small streams take to decode).
+    for (;;) {
+        uint32_t i = 0;
+        if (threadIdx.x == 0) i = atomicAdd(a.counter, 1u);
+        i = uni(i);
+        if (i >= a.n) break;
 #if !defined(PZG_PROFILE)
-    if (a.order) i = a.order[i];
+        if (a.order) i = a.order[i];
 #endif
-    Decoder<RING_BITS> dec(lds);
-    StreamResult r;
-    dec.run(a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i], &r);
-    if (threadIdx.x == 0) {
-        a.status[i] = r.status;
-        a.out_len[i] = r.out_len;
-        if (a.detail) {
-            a.detail[2 * (size_t)i] = r.detail0;
-            a.detail[2 * (size_t)i + 1] = r.detail1;
-        }
-        if (a.in_used) a.in_used[i] = r.in_used;
-        if (a.adler) a.adler[i] = r.adler;
+        // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
+        if (FIXUP && a.status[i] != ST_RETRY_FULL_RING) continue;
+        Decoder<RING_BITS> dec(lds);
+        StreamResult r;
+        dec.run(a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i], &r);
+        if (threadIdx.x == 0) {
+            a.status[i] = r.status;
+            a.out_len[i] = r.out_len;
+            if (a.detail) {
+                a.detail[2 * (size_t)i] = r.detail0;
+                a.detail[2 * (size_t)i + 1] = r.detail1;
+            }
+            if (a.in_used) a.in_used[i] = r.in_used;
+            if (a.adler) a.adler[i] = r.adler;
 #if defined(PZG_PROFILE)
-        // diagnostic build: the 12 phase counters of stream i go to prof_out[12*i ..] (passed in place of `order`)
-        if (a.prof_out)
-            for (int q = 0; q < 16; ++q) a.prof_out[16 * (size_t)i + q] = dec.prof[q];
+            // diagnostic build: the 16 phase counters of stream i go to prof_out[16*i ..]
+            if (a.prof_out)
+                for (int q = 0; q < 16; ++q) a.prof_out[16 * (size_t)i + q] = dec.prof[q];
 #endif
+        }
+        __syncthreads();
     }
 }
 
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
-    dim3 grid(a.n), block(64);
+    hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    // resident stream-waves: LDS bounds the 32 KiB ring to 4 per CU; small rings are VGPR-bound (3 per SIMD)
+    const uint32_t per_cu = ring_bits == 15 ? 4u : ring_bits == 14 ? 7u : ring_bits == 13 ? 10u : 14u;
+    uint32_t waves = 256u * per_cu;
+    if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);  // experiment knob
+    if (waves > a.n) waves = a.n;
+    dim3 grid(waves), block(64);
+    // Ring size classes.  15: the whole 32 KiB DEFLATE window is an LDS ring (4 stream-waves per CU).
+    // 12-14: a smaller near ring plus far back-references served from the stream's own flushed output
+    // (more resident stream-waves per CU; the kernel is latency-bound, so that is what it scales with).
     if (ring_bits == 15)
-        hipLaunchKernelGGL(inflate_kernel<15>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL((inflate_kernel<15, false>), grid, block, 0, stream, a);
+    else if (ring_bits == 14)
+        hipLaunchKernelGGL((inflate_kernel<14, false>), grid, block, 0, stream, a);
+    else if (ring_bits == 13)
+        hipLaunchKernelGGL((inflate_kernel<13, false>), grid, block, 0, stream, a);
+    else if (ring_bits == 12)
+        hipLaunchKernelGGL((inflate_kernel<12, false>), grid, block, 0, stream, a);
     else
         return hipErrorInvalidValue;
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (ring_bits != 15) {
+        // streams whose output outgrew their capacity are redone by the pure-LDS-ring kernel
+        e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        dim3 fgrid(a.n < 1024u ? a.n : 1024u);
+        hipLaunchKernelGGL((inflate_kernel<15, true>), fgrid, block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 

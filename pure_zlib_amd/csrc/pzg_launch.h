@@ -18,6 +18,7 @@ struct InflateArgs {
     uint64_t *in_used;        // n or null
     uint32_t *adler;          // n or null
     const uint32_t *order;    // optional launch permutation (n) or null
+    uint32_t *counter;        // device word the persistent waves draw stream indices from (zeroed per launch)
     uint64_t *prof_out;       // diagnostic builds only (-DPZG_PROFILE): 12 counters per stream, else null
     uint32_t n;
 };

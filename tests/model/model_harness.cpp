@@ -41,13 +41,17 @@ extern "C" {
 int pzm_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, int ring_bits, pzm_result *r)
 {
     if (ring_bits == 15) run_one<15>(in, in_len, out, cap, r);
+    else if (ring_bits == 14) run_one<14>(in, in_len, out, cap, r);
     else if (ring_bits == 13) run_one<13>(in, in_len, out, cap, r);
+    else if (ring_bits == 12) run_one<12>(in, in_len, out, cap, r);
     else return -1;
+    if (r->status == pzg::ST_RETRY_FULL_RING) run_one<15>(in, in_len, out, cap, r);  // what the fixup launch does
     return 0;
 }
 
 uint32_t pzm_lds_bytes(int ring_bits)
 {
-    return ring_bits == 15 ? sizeof(pzg::WaveLds<15>) : sizeof(pzg::WaveLds<13>);
+    return ring_bits == 15 ? sizeof(pzg::WaveLds<15>) : ring_bits == 14 ? sizeof(pzg::WaveLds<14>)
+         : ring_bits == 13 ? sizeof(pzg::WaveLds<13>) : sizeof(pzg::WaveLds<12>);
 }
 }
