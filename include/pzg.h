@@ -86,6 +86,16 @@ int  pzg_set_stream(pzg_ctx *ctx, void *hip_stream);
 int  pzg_reset_stream(pzg_ctx *ctx);
 int  pzg_sync(pzg_ctx *ctx);
 
+/* Tuning options.
+ * PZG_OPT_RING_BITS: log2 of the LDS ring each stream-wave keeps of its most recent output.
+ *   15  the whole 32 KiB DEFLATE window lives in LDS (OutputWindow.hs as a pure LDS ring): 4 stream-waves per CU
+ *   11-14  a smaller near ring; back-references older than it are read from the stream's own, already
+ *       flushed output in HBM/L2.  More stream-waves per CU; the kernel is latency-bound and scales with them.
+ *   Results are bit-identical for every value.  Default: PZG_DEFAULT_RING_BITS. */
+#define PZG_OPT_RING_BITS 1
+#define PZG_DEFAULT_RING_BITS 12
+int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
+
 /*
  * decompressMany: decode n independent zlib (RFC 1950) streams, one wavefront per stream.
  * Replaces n calls of Codec.Compression.Zlib.decompress (Zlib.hs:32-51) on single-chunk inputs.

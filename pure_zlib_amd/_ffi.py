@@ -30,10 +30,12 @@ E_DATA_REMAINING = 15
 
 DEVICE_PTRS = 1
 ASYNC = 2
+OPT_RING_BITS = 1
+DEFAULT_RING_BITS = 12
 
 # every symbol include/pzg.h declares
 SYMBOLS = [
-    "pzg_init", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
+    "pzg_init", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
     "pzg_adler32", "pzg_error_message", "pzg_last_kernel_ms", "pzg_strerror", "pzg_last_error", "pzg_version",
 ]
 
@@ -64,6 +66,8 @@ def lib():
     L.pzg_set_stream.restype = C.c_int
     L.pzg_reset_stream.argtypes = [C.c_void_p]
     L.pzg_reset_stream.restype = C.c_int
+    L.pzg_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    L.pzg_set_option.restype = C.c_int
     L.pzg_sync.argtypes = [C.c_void_p]
     L.pzg_sync.restype = C.c_int
     L.pzg_decompress_many.argtypes = [C.c_void_p, vp, u64p, u64p, vp, u64p, u64p, u64p, i32p, u32p, u64p, u32p,

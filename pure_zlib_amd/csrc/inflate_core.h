@@ -373,9 +373,6 @@ struct Decoder {
         adler_a = (uint32_t)(((uint64_t)adler_a + sum_a) % ADLER_MOD);
         adler_b = (uint32_t)(nb % ADLER_MOD);
         flushed = to;
-#if PZG_DEVICE_PASS
-        if (HYBRID) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // far reads may follow: the stores must have landed
-#endif
         wave_sync();
         PZG_ACC(3, tf);
     }
@@ -402,6 +399,14 @@ struct Decoder {
     // flush_to() waits for its stores, and the load bypasses this CU's L1 (nt), so it sees them.
     static constexpr bool HYBRID = RING_BITS < 15;
     PZG_FN uint8_t fetch_near(uint32_t back) const { return L.ring[((uint32_t)op - back) & RMASK]; }
+    // Before far reads: every flush store of this wave must have landed.  By the time a byte is older
+    // than the ring its flush is long complete, so this wait is normally free.
+    PZG_FN void far_fence() const
+    {
+#if PZG_DEVICE_PASS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    }
     PZG_FN uint8_t fetch_far(bool is_far, uint32_t back) const
     {
         // lanes that are not far (or a count-only stream whose bytes were never stored) read byte 0 of the output
@@ -437,7 +442,10 @@ struct Decoder {
             uint8_t v = L.ring[(src0 + lane) & RMASK];  // lanes >= len read a harmless ring byte
             if (HYBRID) {
                 const bool far = lane < len && dist - lane > RING;
-                if (ballot(far)) v = far ? fetch_far(far, dist - lane) : v;
+                if (ballot(far)) {
+                    far_fence();
+                    v = far ? fetch_far(far, dist - lane) : v;
+                }
             }
             sel_store(lane < len, &L.ring[(dst0 + lane) & RMASK], v, lane);
             op += len;
@@ -466,7 +474,10 @@ struct Decoder {
                 v[c] = L.ring[(src0 + (k < len ? off : 0u)) & RMASK];
                 if (HYBRID) {  // only a non-overlapping match (off == k) can reach past the ring
                     const bool far = k < len && dist - off > RING;
-                    if (ballot(far)) v[c] = far ? fetch_far(far, dist - off) : v[c];
+                    if (ballot(far)) {
+                        far_fence();
+                        v[c] = far ? fetch_far(far, dist - off) : v[c];
+                    }
                 }
             }
         }
@@ -804,6 +815,7 @@ struct Decoder {
                         PZG_LV(FAR, j) = (j < run && (pj & LIT_FLAG) == 0u && pj - j > RING) ? 1u : 0u;
                     PZG_LANES_END
                     if (lanes_ballot(FAR)) {
+                        far_fence();
                         PZG_LANES_BEGIN(j)
                             const bool far = PZG_LV(FAR, j) != 0u;
                             const uint8_t fv = fetch_far(far, PZG_LV(PJ, j) - j);

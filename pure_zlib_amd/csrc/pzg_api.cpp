@@ -39,6 +39,8 @@ struct pzg_ctx {
     std::string last_error;
     void *prof_buf = nullptr;  // diagnostic builds only
     void *d_counter = nullptr; // stream-index counter of the persistent inflate waves
+    int ring_bits = PZG_DEFAULT_RING_BITS;
+    int num_cus = 256;
 };
 
 namespace {
@@ -79,9 +81,7 @@ int launch_timed(pzg_ctx *ctx, const pzg::InflateArgs &args_in)
     pzg::InflateArgs args = args_in;
     args.counter = (uint32_t *)ctx->d_counter;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    int ring_bits = 15;
-    if (const char *e = getenv("PZG_RING_BITS")) ring_bits = atoi(e);  // experiment knob: caller guarantees outputs fit
-    HIP_TRY(ctx, pzg::launch_inflate(args, ring_bits, ctx->stream));
+    HIP_TRY(ctx, pzg::launch_inflate(args, ctx->ring_bits, ctx->num_cus, ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
     return PZG_RC_OK;
@@ -118,6 +118,15 @@ int pzg_init(int device, pzg_ctx **out)
         return PZG_RC_NO_DEVICE;
     }
     ctx->stream = ctx->own_stream;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->num_cus = prop.multiProcessorCount;
+        if (const char *e = getenv("PZG_RING_BITS")) {  // environment override of the default size class
+            const int rb = atoi(e);
+            if (rb >= 11 && rb <= 15) ctx->ring_bits = rb;
+        }
+    }
     if (hipMalloc(&ctx->d_counter, 256) != hipSuccess) {
         delete ctx;
         return PZG_RC_NO_MEMORY;
@@ -155,6 +164,17 @@ int pzg_reset_stream(pzg_ctx *ctx)
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->stream = ctx->own_stream;
     return PZG_RC_OK;
+}
+
+int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
+{
+    if (!ctx) return PZG_RC_BAD_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (option == PZG_OPT_RING_BITS && value >= 11 && value <= 15) {
+        ctx->ring_bits = (int)value;
+        return PZG_RC_OK;
+    }
+    return PZG_RC_BAD_ARG;
 }
 
 int pzg_sync(pzg_ctx *ctx)

@@ -57,14 +57,15 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(InflateArgs a)
     }
 }
 
-hipError_t launch_inflate(const InflateArgs &a, int ring_bits, hipStream_t stream)
+hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    // resident stream-waves: LDS bounds the 32 KiB ring to 4 per CU; small rings are VGPR-bound (3 per SIMD)
-    const uint32_t per_cu = ring_bits == 15 ? 4u : ring_bits == 14 ? 7u : ring_bits == 13 ? 10u : 14u;
-    uint32_t waves = 256u * per_cu;
+    // Resident stream-waves per CU: LDS-bound (160 KiB / sizeof(WaveLds)) for the big rings, VGPR-bound
+    // (<= 128 VGPRs: 4 waves per SIMD) for the small ones.
+    const uint32_t per_cu = ring_bits == 15 ? 4u : ring_bits == 14 ? 7u : ring_bits == 13 ? 10u : ring_bits == 12 ? 14u : 16u;
+    uint32_t waves = (uint32_t)num_cus * per_cu;
     if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);  // experiment knob
     if (waves > a.n) waves = a.n;
     dim3 grid(waves), block(64);
@@ -79,6 +80,8 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, hipStream_t strea
         hipLaunchKernelGGL((inflate_kernel<13, false>), grid, block, 0, stream, a);
     else if (ring_bits == 12)
         hipLaunchKernelGGL((inflate_kernel<12, false>), grid, block, 0, stream, a);
+    else if (ring_bits == 11)
+        hipLaunchKernelGGL((inflate_kernel<11, false>), grid, block, 0, stream, a);
     else
         return hipErrorInvalidValue;
     e = hipGetLastError();

@@ -23,7 +23,7 @@ struct InflateArgs {
     uint32_t n;
 };
 
-hipError_t launch_inflate(const InflateArgs &a, int ring_bits, hipStream_t stream);
+hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);
 
 // partials: 3 * 4 * ceil(max_waves / 4) uint32 of device scratch
 hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *partials, uint32_t max_waves,

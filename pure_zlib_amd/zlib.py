@@ -165,6 +165,10 @@ class Context:
     def reset_stream(self):
         _ffi.check(self._L.pzg_reset_stream(self._h), self._h)
 
+    def set_ring_bits(self, ring_bits: int):
+        """LDS near-ring size class (11..15; 15 = the whole 32 KiB window in LDS).  Results are identical."""
+        _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_RING_BITS, int(ring_bits)), self._h)
+
     def sync(self):
         _ffi.check(self._L.pzg_sync(self._h), self._h)
 

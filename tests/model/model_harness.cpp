@@ -44,6 +44,7 @@ int pzm_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t ca
     else if (ring_bits == 14) run_one<14>(in, in_len, out, cap, r);
     else if (ring_bits == 13) run_one<13>(in, in_len, out, cap, r);
     else if (ring_bits == 12) run_one<12>(in, in_len, out, cap, r);
+    else if (ring_bits == 11) run_one<11>(in, in_len, out, cap, r);
     else return -1;
     if (r->status == pzg::ST_RETRY_FULL_RING) run_one<15>(in, in_len, out, cap, r);  // what the fixup launch does
     return 0;

@@ -1,14 +1,27 @@
-"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the
-reference's own golden vectors.  Bit-exact (integer/byte work): no tolerance anywhere."""
+"""GPU parity tests: the HIP path, called through the C ABI of include/pzg.h, against the oracle, the
+reference's own golden vectors and the pinned generated vectors.  Integer/byte work: bit-exact, no
+tolerance anywhere.  Every parity test runs for the pure 32 KiB LDS ring (15) and for hybrid rings."""
+import hashlib
+import os
+import subprocess
 import zlib
 
 import numpy as np
 import pytest
 
 import corpus
-from conftest import REF_CASES, read_case
+from conftest import REF_CASES, ROOT, read_case
+from test_oracle_golden import load_vectors
 
 pytestmark = pytest.mark.gpu
+RINGS = [15, 13, 12, 11]
+
+
+@pytest.fixture(params=RINGS, ids=lambda r: f"ring{r}")
+def ctx(gpu_ctx, request):
+    gpu_ctx.set_ring_bits(request.param)
+    yield gpu_ctx
+    gpu_ctx.set_ring_bits(12)
 
 
 def run_batch(ctx, streams, caps, align=16):
@@ -33,32 +46,47 @@ def run_batch(ctx, streams, caps, align=16):
 
 
 @pytest.mark.parametrize("name", REF_CASES)
-def test_reference_golden_decompress(gpu_ctx, name):
+def test_reference_golden_decompress(ctx, name):
     """test/Test.hs:83-86: assertEqual (Right gold) (decompress z), through the mirror API."""
     import pure_zlib_amd as P
     z, gold = read_case(name)
-    assert P.decompress(z, ctx=gpu_ctx) == P.Right(gold)
+    assert P.decompress(z, ctx=ctx) == P.Right(gold)
 
 
-def test_reference_golden_batch(gpu_ctx, oracle):
+def test_reference_golden_batch(ctx):
     zs, golds = zip(*[read_case(n) for n in REF_CASES])
-    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(gpu_ctx, list(zs), [len(g) for g in golds])
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, list(zs), [len(g) for g in golds])
     for k, name in enumerate(REF_CASES):
         assert status[k] == 0, name
         assert outs[k] == golds[k], name
-        assert int(out_len[k]) == len(golds[k])
-        assert int(in_used[k]) == len(zs[k])
+        assert int(out_len[k]) == len(golds[k]) and int(in_used[k]) == len(zs[k])
         assert int(adler[k]) == zlib.adler32(golds[k])
 
 
-def test_valid_streams_vs_oracle(gpu_ctx, oracle):
+def test_pinned_generated_vectors(ctx):
+    import pure_zlib_amd.zlib as Z
+    vs = load_vectors()
+    streams = [bytes.fromhex(v["z"]) for v in vs]
+    caps = [max(v["out_len"], 1) for v in vs]
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, caps)
+    for k, v in enumerate(vs):
+        assert status[k] == v["status"], (v["name"], status[k], detail[k])
+        if v["status"] == 0:
+            assert hashlib.sha256(outs[k]).hexdigest() == v["out_sha256"], v["name"]
+            assert int(adler[k]) == v["adler"] and int(in_used[k]) == v["in_used"] and int(out_len[k]) == v["out_len"]
+        else:
+            err = Z.error_from_status(streams[k], int(status[k]), detail[k])
+            assert err.show() == v["message"], (v["name"], err.show(), v["message"])
+
+
+def test_valid_streams_vs_oracle(ctx, oracle):
     streams, datas = [], []
-    for seed in range(600):
+    for seed in range(400):
         n = [0, 1, 2, 5, 100, 1000, 5000, 40000, 70000, 200000][seed % 10] if seed % 7 == 0 else (seed * 37) % 20000
         d = corpus.mixed_data(n, seed)
         streams.append(corpus.compress_variant(d, seed))
         datas.append(d)
-    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(gpu_ctx, streams, [len(d) for d in datas])
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, [len(d) for d in datas])
     for k in range(len(streams)):
         r, o = oracle.decompress(streams[k], len(datas[k]))
         assert r.status == 0 and o == datas[k]
@@ -67,14 +95,14 @@ def test_valid_streams_vs_oracle(gpu_ctx, oracle):
         assert int(adler[k]) == r.adler and int(in_used[k]) == r.in_used and int(out_len[k]) == r.out_len
 
 
-def test_corrupt_streams_vs_oracle(gpu_ctx, oracle):
+def test_corrupt_streams_vs_oracle(ctx, oracle):
     streams, caps = [], []
-    for seed in range(3000):
+    for seed in range(2000):
         d = corpus.mixed_data((seed * 131) % 3000 + 1, seed)
         z = corpus.corrupt(corpus.compress_variant(d, seed), seed)
         streams.append(z)
         caps.append([len(d), len(d) + 100, 1 << 17][seed % 3])
-    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(gpu_ctx, streams, caps)
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, caps)
     import pure_zlib_amd.zlib as Z
     for k in range(len(streams)):
         r, o = oracle.decompress(streams[k], caps[k])
@@ -89,11 +117,24 @@ def test_corrupt_streams_vs_oracle(gpu_ctx, oracle):
             assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())
 
 
-def test_output_never_written_past_capacity(gpu_ctx):
+def test_text_blobs_with_far_back_references(ctx, oracle):
+    """32-100 KiB Zipf text: distances up to 32 KiB, i.e. older than every hybrid ring."""
+    streams, datas = [], []
+    for seed in range(48):
+        n = [32768, 65536, 100000, 4096][seed % 4]
+        d = corpus.zipf_text(n, seed)
+        datas.append(d)
+        streams.append(zlib.compress(d, 1 + seed % 9))
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, [len(d) for d in datas])
+    for k in range(len(streams)):
+        assert status[k] == 0 and outs[k] == datas[k] and int(adler[k]) == zlib.adler32(datas[k]), k
+
+
+def test_output_never_written_past_capacity(ctx):
     d = corpus.zipf_text(50000, 3)
     z = zlib.compress(d, 6)
     caps = [0, 1, 15, 16, 17, 4095, 4096, 32768, 49999]
-    (out_len, status, detail, in_used, adler), outs, out_buf, out_off = run_batch(gpu_ctx, [z] * len(caps), caps)
+    (out_len, status, detail, in_used, adler), outs, out_buf, out_off = run_batch(ctx, [z] * len(caps), caps)
     for k, cap in enumerate(caps):
         assert status[k] == 14 and int(out_len[k]) == len(d)
         assert outs[k] == d[:cap]
@@ -102,25 +143,84 @@ def test_output_never_written_past_capacity(gpu_ctx):
         assert (out_buf[lo:hi] == 0xCD).all()  # padding between extents untouched
 
 
-def test_unaligned_extents(gpu_ctx):
+def test_small_capacity_and_corrupt_trailer(ctx, oracle):
+    """An output larger than its capacity AND a bad checksum: the reference outcome is the checksum error."""
+    d = corpus.zipf_text(40000, 8)
+    z = bytearray(zlib.compress(d, 6))
+    z[-1] ^= 1
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, [bytes(z)] * 3, [100, 20000, 40000])
+    r, _ = oracle.decompress(bytes(z), 100)
+    assert r.status == 10 and list(status) == [10, 10, 10]
+    assert tuple(detail[0]) == (r.detail0, r.detail1)
+
+
+def test_unaligned_extents(ctx):
     streams, datas = [], []
     for seed in range(64):
         d = corpus.mixed_data(1000 + seed * 97, seed + 11)
         datas.append(d)
         streams.append(zlib.compress(d, 1 + seed % 9))
-    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(gpu_ctx, streams, [len(d) for d in datas], align=1)
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, [len(d) for d in datas], align=1)
     for k in range(len(streams)):
         assert status[k] == 0 and outs[k] == datas[k], k
 
 
-def test_adler32_kernel(gpu_ctx, oracle):
+def test_mirror_api_chunks_and_retry(gpu_ctx):
+    """Zlib.hs:37-51 through the mirror: chunked lazy ByteStrings, 'Finished with data remaining.',
+    trailing bytes ignored, outputs larger than the first capacity guess (relaunch with the exact size)."""
+    import pure_zlib_amd as P
+    d = corpus.zipf_text(300000, 2)
+    z = zlib.compress(d, 9)
+    assert P.decompress(z, ctx=gpu_ctx) == P.Right(d)  # 300 KB out of ~90 KB in: needs the retry
+    assert P.decompress([z[:1000], z[1000:50000], z[50000:]], ctx=gpu_ctx) == P.Right(d)
+    assert P.decompress(z + b"tail", ctx=gpu_ctx) == P.Right(d)
+    got = P.decompress([z, b"tail"], ctx=gpu_ctx)
+    assert got == P.Left(P.DecompressionError_("Finished with data remaining."))
+    assert P.decompress(b"", ctx=gpu_ctx) == P.Left(P.DecompressionError_("Ran out of data mid-decompression 2."))
+    many = P.decompressMany([z, z[:-5], b"\x78\x9d", zlib.compress(b"ok")], ctx=gpu_ctx)
+    assert many[0] == P.Right(d) and many[3] == P.Right(b"ok")
+    assert many[1].value.show() == "Decompression error: Ran out of data mid-decompression 2."
+    assert many[2].value.show() == "Header error: Header checksum failed"
+
+
+def test_batch_8192_level6_blobs_every_stream_checked(ctx):
+    """BASELINE config 4 shape (32 KiB level-6 blobs) at 1/8 of the stream count: every stream's status,
+    length, in_used and Adler-32; bench.py repeats this at the full 65,536 with a full byte compare."""
+    pool = [corpus.zipf_text(32768, s) for s in range(64)]
+    zs = [zlib.compress(t, 6) for t in pool]
+    ad = [zlib.adler32(t) for t in pool]
+    n = 8192
+    pick = np.random.default_rng(3).integers(0, 64, size=n)
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, [zs[i] for i in pick], [32768] * n, align=256)
+    assert (status == 0).all() and (out_len == 32768).all()
+    assert (adler == np.array([ad[i] for i in pick], dtype=np.uint32)).all()
+    assert (in_used == np.array([len(zs[i]) for i in pick], dtype=np.uint64)).all()
+    for k in range(0, n, 257):
+        assert outs[k] == pool[pick[k]]
+
+
+def test_adler32_kernel(gpu_ctx):
     rng = np.random.default_rng(5)
-    for n in [0, 1, 15, 16, 17, 1000, 65535, 65536, 65537, 1 << 20, (1 << 22) + 12345, 50_000_000]:
+    for n in [0, 1, 15, 16, 17, 1000, 65535, 65536, 65537, 1 << 20, (1 << 22) + 12345, 50_000_000, 600_000_011]:
         buf = rng.integers(0, 256, size=n + 32, dtype=np.uint8)
         for skew in (0, 3):
             view = buf[skew:skew + n]
-            got = gpu_ctx.adler32(view)
-            assert got == zlib.adler32(view.tobytes()), (n, skew)
+            assert gpu_ctx.adler32(view) == zlib.adler32(view.tobytes()), (n, skew)
     worst = np.full(3_000_000, 255, dtype=np.uint8)
     assert gpu_ctx.adler32(worst) == zlib.adler32(worst.tobytes())
-    assert gpu_ctx.adler32(worst[:70000], init=0xFFF0FFF0 % (1 << 32)) == zlib.adler32(worst[:70000].tobytes(), 0xFFF0FFF0)
+    assert gpu_ctx.adler32(worst[:70000], init=0xFFF0FFF0) == zlib.adler32(worst[:70000].tobytes(), 0xFFF0FFF0)
+
+
+def test_cxx_abi_smoke_binary():
+    """The C ABI from plain C++ (no Python in the loop): tests/cxx/abi_smoke.cpp over the nine fixtures."""
+    exe = os.path.join(ROOT, "tests", "cxx", "abi_smoke")
+    src = os.path.join(ROOT, "tests", "cxx", "abi_smoke.cpp")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe, "-L" + os.path.join(ROOT, "pure_zlib_amd"),
+                               "-lpzg", "-Wl,-rpath," + os.path.join(ROOT, "pure_zlib_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    args = []
+    for n in REF_CASES:
+        args += [os.path.join(ROOT, "tests", "golden", "ref", n + ".z"), os.path.join(ROOT, "tests", "golden", "ref", n + ".gold")]
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(" OK ") == len(REF_CASES)

@@ -1,0 +1,107 @@
+"""CPU: the kernel source itself (pure_zlib_amd/csrc/inflate_core.h) compiled as a host program
+(wave.h: one host thread, 64-lane LaneVecs emulated) and checked against the oracle.  This pins
+the kernel's control logic, table construction, window/segment logic, hybrid near/far window and
+error ordering without a GPU.  The model is test infrastructure; libpzg.so never contains it."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import zlib
+
+import pytest
+
+import corpus
+from conftest import REF_CASES, ROOT, read_case
+from test_oracle_golden import load_vectors
+
+RINGS = [15, 13, 12, 11]
+
+
+class R(C.Structure):
+    _fields_ = [("status", C.c_int32), ("detail0", C.c_uint32), ("detail1", C.c_uint32), ("adler", C.c_uint32),
+                ("out_len", C.c_uint64), ("in_used", C.c_uint64)]
+
+
+@pytest.fixture(scope="session")
+def model():
+    d = os.path.join(ROOT, "tests", "model")
+    so = os.path.join(d, "libpzgmodel.so")
+    srcs = [os.path.join(d, "model_harness.cpp"), os.path.join(ROOT, "pure_zlib_amd", "csrc", "inflate_core.h"),
+            os.path.join(ROOT, "pure_zlib_amd", "csrc", "wave.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
+    M = C.CDLL(so)
+    M.pzm_decompress.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(R)]
+
+    def run(z, cap, rb):
+        out = C.create_string_buffer(max(cap, 1))
+        r = R()
+        assert M.pzm_decompress(z, len(z), out, cap, rb, C.byref(r)) == 0
+        return r, out.raw[: min(r.out_len, cap)]
+    return run
+
+
+def same(ro, oo, rm, om):
+    if ro.status != rm.status:
+        return False
+    if ro.status == 0:
+        return oo == om and ro.adler == rm.adler and ro.in_used == rm.in_used and ro.out_len == rm.out_len
+    if ro.status == 14:
+        return ro.out_len == rm.out_len
+    if ro.status in (3, 4, 6, 10, 11, 12, 13):
+        return (ro.detail0, ro.detail1) == (rm.detail0, rm.detail1)
+    if ro.status == 7:
+        return (ro.detail0 & 0xff) == rm.detail0
+    return True
+
+
+@pytest.mark.parametrize("rb", RINGS)
+def test_model_reference_gold_files(model, rb):
+    for name in REF_CASES:
+        z, gold = read_case(name)
+        r, out = model(z, len(gold), rb)
+        assert r.status == 0 and out == gold and r.in_used == len(z) and r.adler == zlib.adler32(gold), name
+
+
+@pytest.mark.parametrize("rb", RINGS)
+def test_model_pinned_vectors(model, rb):
+    for v in load_vectors():
+        z = bytes.fromhex(v["z"])
+        r, out = model(z, 1 << 21, rb)
+        assert r.status == v["status"], v["name"]
+        assert r.out_len == v["out_len"] or v["status"] != 0
+        if v["status"] == 0:
+            assert hashlib.sha256(out).hexdigest() == v["out_sha256"] and r.adler == v["adler"] and r.in_used == v["in_used"]
+        if v["status"] in (3, 4, 6, 10, 11, 12, 13):
+            assert [r.detail0, r.detail1] == v["detail"], v["name"]
+
+
+@pytest.mark.parametrize("rb", [15, 12])
+def test_model_fuzz_valid_and_corrupt(model, oracle, rb):
+    for seed in range(250):
+        n = [0, 1, 2, 5, 100, 1000, 5000, 40000, 70000][seed % 9] if seed % 7 == 0 else (seed * 37) % 12000
+        d = corpus.mixed_data(n, seed)
+        z = corpus.compress_variant(d, seed)
+        r, out = model(z, len(d), rb)
+        assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), seed
+    for seed in range(1200):
+        d = corpus.mixed_data((seed * 131) % 3000 + 1, seed)
+        z = corpus.corrupt(corpus.compress_variant(d, seed), seed)
+        cap = [len(d), len(d) + 100, 1 << 17][seed % 3]
+        ro, oo = oracle.decompress(z, cap)
+        rm, om = model(z, cap, rb)
+        assert same(ro, oo, rm, om), (seed, ro.status, rm.status, ro.message)
+
+
+@pytest.mark.parametrize("rb", [13, 12, 11])
+def test_model_far_window_and_small_capacity(model, oracle, rb):
+    """Back-references older than the LDS ring come from the flushed output; an output larger than
+    its capacity is handed to the 32 KiB-ring pass (the harness does what the fixup launch does)."""
+    for seed in range(16):
+        n = [32768, 65536, 100000, 5000][seed % 4]
+        d = corpus.zipf_text(n, seed) if seed % 2 == 0 else (corpus.random_bytes(3000, seed) + corpus.zipf_text(20000, seed) + corpus.random_bytes(3000, seed) * 3)
+        z = zlib.compress(d, 1 + seed % 9)
+        for cap in (len(d), len(d) // 2, 0):
+            ro, oo = oracle.decompress(z, cap)
+            rm, om = model(z, cap, rb)
+            assert (ro.status, ro.out_len) == (rm.status, rm.out_len) and oo == om, (seed, cap)
