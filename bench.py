@@ -38,6 +38,20 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def traffic_from_profiles(args, ring_bits, n):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs)
+    of this same command; recorded in profiles/traffic.json by hand after each profiling session."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        for e in t["entries"]:
+            if e["workload"] == args.workload and e["ring_bits"] == ring_bits and e["streams"] == n:
+                return e["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def build_pool(args):
     """P distinct (text, zlib stream) pairs, seeds 0..P-1, identical on every rank."""
     texts, zs = [], []
@@ -70,6 +84,8 @@ def main():
     ap.add_argument("--pool", type=int, default=2048, help="distinct blobs; the batch replicates them at distinct addresses")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="streams timed on the CPU baseline (rank 0, N=1)")
     ap.add_argument("--adler-gib", type=float, default=16.0, help="Adler-32 microbench size (BASELINE config 2); 0 = skip")
+    ap.add_argument("--ring-bits", type=int, default=0, help="LDS ring size class 11..15 (0 = library default); 15 = the whole 32 KiB window in LDS")
+    ap.add_argument("--no-ab", action="store_true", help="skip the secondary measurement of the pure 32 KiB LDS-ring variant")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
@@ -128,6 +144,9 @@ def main():
 
     ctx = P.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    from pure_zlib_amd import _ffi
+    ring_bits = args.ring_bits or int(os.environ.get("PZG_RING_BITS", _ffi.DEFAULT_RING_BITS))
+    ctx.set_ring_bits(ring_bits)
 
     def step():
         ctx.decompress_many_device(d_in.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), d_out.data_ptr(),
@@ -190,6 +209,22 @@ def main():
             bad = np.nonzero(status != 0)[0]
             log(f"[bench] rank {rank}: VERIFICATION FAILED; {len(bad)} bad statuses, first {bad[:5]} {status[bad[:5]]}")
 
+    # ---- A/B evidence: the same batch through the pure 32 KiB LDS-ring variant (north_star's literal design) ----
+    ab = None
+    if rank == 0 and world == 1 and not args.no_ab and ring_bits != 15:
+        ctx.set_ring_bits(15)
+        step()
+        torch.cuda.synchronize()
+        ms15 = []
+        for _ in range(2):
+            step()
+            ms15.append(ctx.last_kernel_ms())
+        ok15 = bool((d_status.cpu().numpy() == 0).all() and (d_adler.cpu().numpy().view(np.uint32) == exp_adler).all()) if not args.no_verify else None
+        ab = {"ring_bits": 15, "kernel_ms": round(float(np.mean(ms15)), 3),
+              "GiBps": round(int(out_cap.sum()) / (float(np.mean(ms15)) * 1e-3) / 2**30, 2), "bit_exact": ok15,
+              "note": "whole DEFLATE window as an LDS ring: 4 stream-waves per CU (LDS-bound occupancy)"}
+        ctx.set_ring_bits(ring_bits)
+
     dec_total = int(out_cap.sum()) * world  # decoded bytes per step, whole job (every rank holds the same amount)
     comp_total = int(in_len.sum())
     value = dec_total * args.steps / elapsed / 2**30
@@ -216,7 +251,7 @@ def main():
             "config": {
                 "workload": {
                     "l6_32k": f"BASELINE config 4: {args.streams} x {args.blob_bytes // 1024} KiB level-{args.level} "
-                              "dynamic-Huffman zlib blobs per GPU, one stream per wavefront, 32 KiB LDS ring",
+                              "dynamic-Huffman zlib blobs per GPU, one stream per wavefront",
                     "fixed_4k": f"BASELINE config 3: {args.streams} x 4 KiB fixed-Huffman (Z_FIXED level-1) blobs per GPU",
                     "mixed": f"BASELINE config 5 shape: {args.streams} mixed 1-64 KiB level-6 blobs per GPU",
                 }[args.workload],
@@ -225,11 +260,13 @@ def main():
                 "compressed_MiB_per_gpu": round(comp_total / 2**20, 1),
                 "decompressed_MiB_per_gpu": round(int(out_cap.sum()) / 2**20, 1),
                 "parallelism": f"shard{world}" if world > 1 else "single",
+                "ring_bits": ring_bits,
+                "window": "32 KiB LDS ring" if ring_bits == 15 else f"{2**ring_bits // 1024} KiB LDS near ring + far back-references from the stream's flushed output (HBM/L2)",
                 "verified": "every stream: status, length, in_used, Adler-32 and full byte compare" if bit_exact is not None else "skipped",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "inflate_kernel<15>",
+                "kernel": f"inflate_kernel<{ring_bits},false>",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -238,9 +275,11 @@ def main():
                 "read_only_GBps": round(comp_total / (k_ms * 1e-3) / 1e9, 2),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": round(k_ms, 4),
-                "traffic": None,
+                "traffic": traffic_from_profiles(args, ring_bits, n),
             },
         }
+        if ab is not None:
+            result["lds_ring_32k_variant"] = ab
 
     # ---- CPU baseline: the oracle ("port") on a bounded sample, rank 0 at N=1 only -----------------
     if rank == 0 and world == 1 and args.cpu_sample > 0:

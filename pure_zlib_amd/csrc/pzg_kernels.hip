@@ -21,6 +21,7 @@ template <int RING_BITS, bool FIXUP>
 __global__ __launch_bounds__(64, 4) void inflate_kernel(InflateArgs a)
 {
     __shared__ WaveLds<RING_BITS> lds;
+    if (FIXUP && __builtin_nontemporal_load(a.counter + 1) == 0u) return;  // nothing was handed back
     // Persistent stream-waves: the grid is sized to the residency of the chip and every wave pulls
     // stream indices from one device-scope counter until the batch is drained (a returning atomic is
     // ~0.3-1 us, nothing next to a >= 50 us stream; launching one workgroup per stream instead costs
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(InflateArgs a)
         dec.run(a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i], &r);
         if (threadIdx.x == 0) {
             a.status[i] = r.status;
+            if (!FIXUP && r.status == ST_RETRY_FULL_RING) atomicAdd(a.counter + 1, 1u);
             a.out_len[i] = r.out_len;
             if (a.detail) {
                 a.detail[2 * (size_t)i] = r.detail0;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(InflateArgs a)
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back
     if (e != hipSuccess) return e;
     // Resident stream-waves per CU: LDS-bound (160 KiB / sizeof(WaveLds)) for the big rings, VGPR-bound
     // (<= 128 VGPRs: 4 waves per SIMD) for the small ones.
