@@ -706,8 +706,24 @@ struct Decoder {
 #endif
         // ---- phase A (all lanes): lane k decodes the token that would start k bits ahead ----------
         const uint32_t i0 = (uint32_t)(br.pos >> 5), boff = (uint32_t)br.pos & 31u;
-        const uint32_t B0 = br.dword(i0), B1 = br.dword(i0 + 1u), B2 = br.dword(i0 + 2u), B3 = br.dword(i0 + 3u),
-                       B4 = br.dword(i0 + 4u);
+        uint32_t B0, B1, B2, B3, B4;
+#if PZG_DEVICE_PASS
+        const uint32_t li = i0 - br.chunk0;  // < 64 (slide() keeps the cursor's dword inside `cur`)
+        if (li <= 59u) {                     // all five dwords sit in the current chunk register
+            B0 = read_lane(br.cur, li);
+            B1 = read_lane(br.cur, li + 1u);
+            B2 = read_lane(br.cur, li + 2u);
+            B3 = read_lane(br.cur, li + 3u);
+            B4 = read_lane(br.cur, li + 4u);
+        } else
+#endif
+        {
+            B0 = br.dword(i0);
+            B1 = br.dword(i0 + 1u);
+            B2 = br.dword(i0 + 2u);
+            B3 = br.dword(i0 + 3u);
+            B4 = br.dword(i0 + 4u);
+        }
         constexpr uint32_t LIT_FLAG = 0x80000000u, F_OTHER = 1u << 24, F_LIT = 1u << 25;
         LaneVec<uint32_t> INFO;  // [7:0] token bits (64 for a token the walk must stop at)  [16:8] output bytes  [24] other  [25] literal
         LaneVec<uint32_t> PV;    // literal: LIT_FLAG | byte    match: distance
@@ -868,7 +884,6 @@ struct Decoder {
     PZG_FN int token_loop()
     {
         for (;;) {
-            pin_uniform();
             if (br.avail() >= WINDOW_MIN_BITS) {
                 const uint64_t before = br.pos;
                 PZG_T0(tw);
