@@ -140,6 +140,8 @@ struct alignas(16) WaveLds {
     uint8_t lens[MAX_LENS + 22];         // code lengths of the block being set up
     uint8_t cl_lens[20];                 // code-length code lengths in symbol order
     uint8_t mk[64];                      // window_step's byte->token marker; all zero between segments
+    uint32_t fixed_ready;                // 0x51DF1BED while lit/dist tables hold the fixed code: survives from one stream to the
+                                         // next on a persistent wave, so a batch of fixed-Huffman streams builds it once per wave
     uint8_t dump[64 + 12];               // where masked-off lanes store (see sel_store): keeps hot loops free of lane-dependent branches
 };
 
@@ -257,7 +259,6 @@ struct Decoder {
     uint64_t flushed;   // bytes already written to HBM and folded into the Adler state
     uint32_t adler_a, adler_b;
     uint32_t lit_e15, dist_e15;  // Kraft totals in 2^-15 units (0 = empty tree)
-    int fixed_loaded;            // lit/dist tables currently hold the fixed code
     int32_t status;
     uint32_t detail0, detail1;
 #if defined(PZG_PROFILE)
@@ -283,7 +284,6 @@ struct Decoder {
         adler_b = uni(adler_b);
         lit_e15 = uni(lit_e15);
         dist_e15 = uni(dist_e15);
-        fixed_loaded = (int)uni((uint32_t)fixed_loaded);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
 #endif
@@ -934,9 +934,13 @@ struct Decoder {
     }
 
     // ---- Deflate.hs:79-82,241-251: the fixed code ---------------------------------------------------
+    static constexpr uint32_t FIXED_MAGIC = 0x51DF1BEDu;
     PZG_FN void load_fixed_tables()
     {
-        if (fixed_loaded) return;
+        if (uni(L.fixed_ready) == FIXED_MAGIC) {  // still there from an earlier block or stream of this wave
+            lit_e15 = dist_e15 = 32768u;
+            return;
+        }
         const uint32_t lane = lane_id();
 #pragma nounroll
         for (uint32_t s0 = 0; s0 < 320u; s0 += PZG_WAVE) {
@@ -945,7 +949,8 @@ struct Decoder {
         }
         build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, L.lit_sorted, &L.lit_meta, &lit_e15);
         build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, L.dist_sorted, &L.dist_meta, &dist_e15);
-        fixed_loaded = 1;
+        if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = FIXED_MAGIC;
+        wave_sync();
     }
 
     // ---- Deflate.hs:83-101,124-156: dynamic block header ---------------------------------------------
@@ -980,6 +985,7 @@ struct Decoder {
             }
             br.drop(3u * m);
         }
+        if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = 0u;  // the tables are about to be overwritten
         uint32_t cl_e15;
         if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, nullptr, &L.cl_meta, &cl_e15))
             return fail(ST_HUFF_BUILD, TREE_CODELEN, block_bit);
@@ -1025,7 +1031,6 @@ struct Decoder {
             return fail(ST_HUFF_BUILD, TREE_LITLEN, block_bit);
         if (!build_table<DIST_BITS, TREE_DIST>(L.lens + hlit, n - hlit, L.dist_lut, L.dist_sorted, &L.dist_meta, &dist_e15))
             return fail(ST_HUFF_BUILD, TREE_DIST, block_bit);
-        fixed_loaded = 0;
         return ST_OK;
     }
 
@@ -1041,7 +1046,6 @@ struct Decoder {
         adler_a = 1;
         adler_b = 0;
         lit_e15 = dist_e15 = 0;
-        fixed_loaded = 0;
         status = ST_OK;
         detail0 = detail1 = 0;
         in_byte0 = 0;

@@ -22,6 +22,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(InflateArgs a)
 {
     __shared__ WaveLds<RING_BITS> lds;
     if (FIXUP && __builtin_nontemporal_load(a.counter + 1) == 0u) return;  // nothing was handed back
+    if (threadIdx.x == 0) lds.fixed_ready = 0u;  // LDS is not zeroed at launch
+    __syncthreads();
     // Persistent stream-waves: the grid is sized to the residency of the chip and every wave pulls
     // stream indices from one device-scope counter until the batch is drained (a returning atomic is
     // ~0.3-1 us, nothing next to a >= 50 us stream; launching one workgroup per stream instead costs
