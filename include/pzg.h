@@ -93,7 +93,7 @@ int  pzg_sync(pzg_ctx *ctx);
  *       flushed output in HBM/L2.  More stream-waves per CU; the kernel is latency-bound and scales with them.
  *   Results are bit-identical for every value.  Default: PZG_DEFAULT_RING_BITS. */
 #define PZG_OPT_RING_BITS 1
-#define PZG_DEFAULT_RING_BITS 12
+#define PZG_DEFAULT_RING_BITS 11
 int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
 
 /*

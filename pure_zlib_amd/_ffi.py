@@ -31,7 +31,7 @@ E_DATA_REMAINING = 15
 DEVICE_PTRS = 1
 ASYNC = 2
 OPT_RING_BITS = 1
-DEFAULT_RING_BITS = 12
+DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares
 SYMBOLS = [

@@ -131,8 +131,6 @@ struct alignas(16) WaveLds {
     uint8_t ring[1u << RING_BITS];       // OutputWindow: the last 2^RING_BITS bytes produced
     uint32_t lit_lut[1u << LIT_BITS];    // HuffmanTree (literal/length), level 1
     uint32_t dist_lut[1u << DIST_BITS];  // HuffmanTree (distance), level 1; the code-length LUT while a header is read
-    uint16_t lit_sorted[MAX_LIT_SYMS];   // level 2: symbols in canonical order
-    uint16_t dist_sorted[MAX_DIST_SYMS + 6];
     TreeMeta lit_meta;
     TreeMeta dist_meta;
     TreeMeta cl_meta;
@@ -259,6 +257,7 @@ struct Decoder {
     uint64_t flushed;   // bytes already written to HBM and folded into the Adler state
     uint32_t adler_a, adler_b;
     uint32_t lit_e15, dist_e15;  // Kraft totals in 2^-15 units (0 = empty tree)
+    uint32_t lit_n, dist_n;      // symbols of the current block's two codes: lens[0..lit_n) and lens[lit_n..lit_n+dist_n)
     int32_t status;
     uint32_t detail0, detail1;
 #if defined(PZG_PROFILE)
@@ -284,6 +283,8 @@ struct Decoder {
         adler_b = uni(adler_b);
         lit_e15 = uni(lit_e15);
         dist_e15 = uni(dist_e15);
+        lit_n = uni(lit_n);
+        dist_n = uni(dist_n);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
 #endif
@@ -379,7 +380,7 @@ struct Decoder {
 
     PZG_FN void maybe_flush()
     {
-        if (op - flushed >= FLUSH_AT) flush_to(op & ~(uint64_t)15u);
+        if ((uint32_t)(op - flushed) >= FLUSH_AT) flush_to(op & ~(uint64_t)15u);  // the difference never exceeds RING
     }
 
     // Lane-predicated LDS byte store WITHOUT a branch: lanes whose predicate is false store into a
@@ -494,8 +495,7 @@ struct Decoder {
     // per-length first/count/offset table.  Returns false when the code is over-subscribed,
     // which is exactly when createHuffmanTree returns Left (any overlap of canonical codes).
     template <int P, int TREE>
-    PZG_FN bool build_table(const uint8_t *lens, uint32_t n, uint32_t *lut, uint16_t *sorted, TreeMeta *meta,
-                            uint32_t *e15_out)
+    PZG_FN bool build_table(const uint8_t *lens, uint32_t n, uint32_t *lut, TreeMeta *meta, uint32_t *e15_out)
     {
         const uint32_t lane = lane_id();
         // pass 1: histogram of code lengths (blCount, Deflate.hs:266)
@@ -580,7 +580,6 @@ struct Decoder {
             }
             if (len != 0u) {
                 const uint32_t c = (uint32_t)meta->first[len] + rank;
-                if (sorted) sorted[(uint32_t)meta->offs[len] + rank] = (uint16_t)s;
                 if (len <= (uint32_t)P) {
                     uint32_t ent = TREE == TREE_LITLEN ? litlen_entry(s, len)
                                    : TREE == TREE_DIST ? dist_entry(s, len)
@@ -596,19 +595,36 @@ struct Decoder {
     }
 
     // Second level (codes longer than the primary table): canonical first-code walk, one length
-    // per step, equivalent to HuffmanTree.hs:73-83 advanceTree on the same bits.  Returns an entry.
+    // per step, equivalent to HuffmanTree.hs:73-83 advanceTree on the same bits.  The symbol with
+    // canonical index `idx` among those of length l is found by a ballot scan of the block's code
+    // lengths, which stay in LDS for the whole block (no sorted-symbol table: LDS is what bounds the
+    // number of resident stream-waves).  Returns an entry.
     template <int TREE>
-    PZG_FN uint32_t decode_long(uint32_t bits, const TreeMeta *meta, const uint16_t *sorted, uint32_t e15)
+    PZG_FN uint32_t decode_long(uint32_t bits, const TreeMeta *meta, const uint8_t *lens, uint32_t nsym, uint32_t e15)
     {
         uint32_t code = 0;
 #pragma nounroll
         for (uint32_t l = 1; l < 16u; ++l) {
             code = (code << 1) | (bits & 1u);
             bits >>= 1;
-            uint32_t cnt_l = uni(meta->count[l]);
-            uint32_t first_l = uni(meta->first[l]);
+            const uint32_t cnt_l = uni(meta->count[l]);
+            const uint32_t first_l = uni(meta->first[l]);
             if (code - first_l < cnt_l && code >= first_l) {
-                uint32_t sym = uni(sorted[uni(meta->offs[l]) + code - first_l]);
+                uint32_t want = code - first_l, sym = 0;
+                const uint32_t lane = lane_id();
+#pragma nounroll
+                for (uint32_t s0 = 0; s0 < nsym; s0 += PZG_WAVE) {
+                    const uint32_t s = s0 + lane;
+                    const bool mine = s < nsym && lens[s < nsym ? s : 0u] == l;
+                    const uint64_t m = ballot(mine);
+                    const uint32_t c = popc64(m);
+                    if (want < c) {
+                        const uint64_t hit = ballot(mine && mbcnt(m) == want);
+                        sym = s0 + ctz64(hit);
+                        break;
+                    }
+                    want -= c;
+                }
                 return TREE == TREE_LITLEN ? litlen_entry(sym, l) : dist_entry(sym, l);
             }
             if ((code << (15u - l)) >= e15) return mk_entry(l, 0, K_EMPTY_BRANCH, 0);
@@ -646,7 +662,7 @@ struct Decoder {
         uint32_t e = uni(L.lit_lut[bits & ((1u << LIT_BITS) - 1u)]);
         uint32_t kind = ent_kind(e);
         if (kind == K_LONG) {
-            e = decode_long<TREE_LITLEN>(bits, &L.lit_meta, L.lit_sorted, lit_e15);
+            e = decode_long<TREE_LITLEN>(bits, &L.lit_meta, L.lens, lit_n, lit_e15);
             kind = ent_kind(e);
         }
         if (kind == K_LIT) {
@@ -666,7 +682,7 @@ struct Decoder {
             uint32_t d = uni(L.dist_lut[bits & ((1u << DIST_BITS) - 1u)]);
             uint32_t dk = ent_kind(d);
             if (dk == K_LONG) {
-                d = decode_long<TREE_DIST>(bits, &L.dist_meta, L.dist_sorted, dist_e15);
+                d = decode_long<TREE_DIST>(bits, &L.dist_meta, L.lens + lit_n, dist_n, dist_e15);
                 dk = ent_kind(d);
             }
             if (dk != K_BASE) {
@@ -759,7 +775,11 @@ struct Decoder {
         uint64_t S = 0;
         uint32_t kend = 0;
         do {
+#if PZG_DEVICE_PASS
+            asm("s_bitset1_b64 %0, %1" : "+s"(S) : "s"(kend));  // S |= 1 << kend in one SALU op
+#else
             S |= 1ull << kend;
+#endif
             kend += lane_get(INFO, kend) & 0xffu;
         } while (kend < 64u);
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
@@ -937,6 +957,8 @@ struct Decoder {
     static constexpr uint32_t FIXED_MAGIC = 0x51DF1BEDu;
     PZG_FN void load_fixed_tables()
     {
+        lit_n = 288u;  // (no fixed code is longer than its primary table, so lens is never consulted for it)
+        dist_n = 32u;
         if (uni(L.fixed_ready) == FIXED_MAGIC) {  // still there from an earlier block or stream of this wave
             lit_e15 = dist_e15 = 32768u;
             return;
@@ -947,8 +969,8 @@ struct Decoder {
             const uint32_t s = s0 + lane;
             if (s < 320u) L.lens[s] = (uint8_t)(s <= 143u ? 8u : s <= 255u ? 9u : s <= 279u ? 7u : s <= 287u ? 8u : 5u);
         }
-        build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, L.lit_sorted, &L.lit_meta, &lit_e15);
-        build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, L.dist_sorted, &L.dist_meta, &dist_e15);
+        build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, &L.lit_meta, &lit_e15);
+        build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, &L.dist_meta, &dist_e15);
         if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = FIXED_MAGIC;
         wave_sync();
     }
@@ -986,8 +1008,9 @@ struct Decoder {
             br.drop(3u * m);
         }
         if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = 0u;  // the tables are about to be overwritten
+        lit_n = hlit;
         uint32_t cl_e15;
-        if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, nullptr, &L.cl_meta, &cl_e15))
+        if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, &L.cl_meta, &cl_e15))
             return fail(ST_HUFF_BUILD, TREE_CODELEN, block_bit);
         // getCodeLengths (Deflate.hs:124-156) over HLIT+HDIST as ONE sequence
         const uint32_t maxl = hlit + hdist;
@@ -1027,9 +1050,10 @@ struct Decoder {
         }
         wave_sync();
         // litTree first, then distTree (Deflate.hs:98-99): errors surface in that order
-        if (!build_table<LIT_BITS, TREE_LITLEN>(L.lens, hlit, L.lit_lut, L.lit_sorted, &L.lit_meta, &lit_e15))
+        if (!build_table<LIT_BITS, TREE_LITLEN>(L.lens, hlit, L.lit_lut, &L.lit_meta, &lit_e15))
             return fail(ST_HUFF_BUILD, TREE_LITLEN, block_bit);
-        if (!build_table<DIST_BITS, TREE_DIST>(L.lens + hlit, n - hlit, L.dist_lut, L.dist_sorted, &L.dist_meta, &dist_e15))
+        dist_n = n - hlit;
+        if (!build_table<DIST_BITS, TREE_DIST>(L.lens + hlit, n - hlit, L.dist_lut, &L.dist_meta, &dist_e15))
             return fail(ST_HUFF_BUILD, TREE_DIST, block_bit);
         return ST_OK;
     }
@@ -1046,6 +1070,7 @@ struct Decoder {
         adler_a = 1;
         adler_b = 0;
         lit_e15 = dist_e15 = 0;
+        lit_n = dist_n = 0;
         status = ST_OK;
         detail0 = detail1 = 0;
         in_byte0 = 0;

@@ -18,7 +18,7 @@ namespace pzg {
 // inflate: grid = number of streams, block = 64 threads.  LDS per workgroup = sizeof(WaveLds) =
 // 38.7 KiB at RING_BITS = 15, so four stream-waves are resident per CU (one per SIMD).
 template <int RING_BITS, bool FIXUP>
-__global__ __launch_bounds__(64, 4) void inflate_kernel(InflateArgs a)
+__global__ __launch_bounds__(64, (RING_BITS <= 11 ? 5 : 4)) void inflate_kernel(InflateArgs a)
 {
     __shared__ WaveLds<RING_BITS> lds;
     if (FIXUP && __builtin_nontemporal_load(a.counter + 1) == 0u) return;  // nothing was handed back
@@ -67,8 +67,8 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     hipError_t e = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back
     if (e != hipSuccess) return e;
     // Resident stream-waves per CU: LDS-bound (160 KiB / sizeof(WaveLds)) for the big rings, VGPR-bound
-    // (<= 128 VGPRs: 4 waves per SIMD) for the small ones.
-    const uint32_t per_cu = ring_bits == 15 ? 4u : ring_bits == 14 ? 7u : ring_bits == 13 ? 10u : ring_bits == 12 ? 14u : 16u;
+    // (<= 128 VGPRs: 4 waves per SIMD; <= 96 for ring 11: 5 per SIMD) for the small ones.
+    const uint32_t per_cu = ring_bits == 15 ? 4u : ring_bits == 14 ? 7u : ring_bits == 13 ? 11u : ring_bits == 12 ? 16u : 20u;
     uint32_t waves = (uint32_t)num_cus * per_cu;
     if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);  // experiment knob
     if (waves > a.n) waves = a.n;

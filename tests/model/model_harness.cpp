@@ -53,6 +53,6 @@ int pzm_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t ca
 uint32_t pzm_lds_bytes(int ring_bits)
 {
     return ring_bits == 15 ? sizeof(pzg::WaveLds<15>) : ring_bits == 14 ? sizeof(pzg::WaveLds<14>)
-         : ring_bits == 13 ? sizeof(pzg::WaveLds<13>) : sizeof(pzg::WaveLds<12>);
+         : ring_bits == 13 ? sizeof(pzg::WaveLds<13>) : ring_bits == 12 ? sizeof(pzg::WaveLds<12>) : sizeof(pzg::WaveLds<11>);
 }
 }

@@ -21,7 +21,7 @@ RINGS = [15, 13, 12, 11]
 def ctx(gpu_ctx, request):
     gpu_ctx.set_ring_bits(request.param)
     yield gpu_ctx
-    gpu_ctx.set_ring_bits(12)
+    gpu_ctx.set_ring_bits(11)
 
 
 def run_batch(ctx, streams, caps, align=16):
