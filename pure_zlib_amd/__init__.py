@@ -5,6 +5,7 @@ Only what the hot path needs lives here:
   csrc/      hand-written HIP kernels (gfx950) + the C ABI of include/pzg.h  -> libpzg.so
   zlib.py    host-side mirror of the reference module Codec.Compression.Zlib
   shard.py   host-side sharding of a batch of streams over the GPUs of a node
+  incremental.py, deflate_cli.py   the reference's streaming protocol and CLI over the same path
 
 There is no CPU fallback: importing works anywhere, computing needs libpzg.so and a gfx950 device.
 """

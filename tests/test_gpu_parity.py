@@ -224,3 +224,40 @@ def test_cxx_abi_smoke_binary():
     out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(" OK ") == len(REF_CASES)
+
+
+def test_incremental_protocol_and_cli(gpu_ctx, tmp_path, capsys):
+    """ZlibDecoder protocol (Monad.hs:163-167) and the deflate CLI (Deflate.hs:15-48)."""
+    from pure_zlib_amd import deflate_cli
+    from pure_zlib_amd.incremental import Chunk, DecompError, Done, NeedMore, decompress_incremental
+    d = corpus.zipf_text(150000, 4)
+    z = zlib.compress(d, 6)
+    st = decompress_incremental(gpu_ctx)
+    assert isinstance(st, NeedMore)
+    st = st.feed(b"")
+    assert isinstance(st, NeedMore)
+    pieces = [z[i:i + 7000] for i in range(0, len(z), 7000)]
+    for p in pieces[:-1]:
+        st = st.feed(p)
+        assert isinstance(st, NeedMore)
+    st = st.feed(pieces[-1])
+    got = []
+    while isinstance(st, Chunk):
+        got.append(st.chunk)
+        st = st.next()
+    assert isinstance(st, Done) and b"".join(got) == d
+    assert [len(c) for c in got[:-1]] == [32768] * (len(got) - 1) and 32768 <= len(got[-1]) < 65536
+    bad = decompress_incremental(gpu_ctx).feed(b"\x78\x9d\x00")
+    assert isinstance(bad, DecompError) and bad.error.show() == "Header error: Header checksum failed"
+    # the CLI
+    src = tmp_path / "blob.z"
+    src.write_bytes(z)
+    assert deflate_cli.main([str(src)]) == 0
+    assert (tmp_path / "blob").read_bytes() == d
+    deflate_cli.main([str(tmp_path / "blob.txt")])
+    deflate_cli.main([])
+    (tmp_path / "cut.z").write_bytes(z[:-9])
+    deflate_cli.main([str(tmp_path / "cut.z")])
+    out = capsys.readouterr().out
+    assert "Unexpected file name." in out and "USAGE: deflate [filename]" in out
+    assert "ERROR: Ran out of data mid-decompression." in out
