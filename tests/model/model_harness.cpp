@@ -22,7 +22,7 @@ static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t c
     // pad the input on both sides: the bit reader loads whole aligned dwords
     uint8_t *buf = (uint8_t *)malloc(in_len + 16);
     memset(buf, 0xEE, in_len + 16);
-    memcpy(buf + 8, in, in_len);
+    if (in_len) memcpy(buf + 8, in, in_len);
     pzg::Decoder<RB> dec(*lds);
     pzg::StreamResult sr;
     dec.run(buf + 8, in_len, out, cap, &sr);
