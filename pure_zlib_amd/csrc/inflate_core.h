@@ -32,9 +32,11 @@
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
 #define PZG_T0(var) const uint64_t var = __builtin_amdgcn_s_memtime()
 #define PZG_ACC(slot, var) prof[slot] += __builtin_amdgcn_s_memtime() - var
+#define PZG_ACCW(slot, var) (__builtin_amdgcn_s_waitcnt(0xc07f), prof[slot] += __builtin_amdgcn_s_memtime() - var)  // after lgkmcnt(0)
 #else
 #define PZG_T0(var)
 #define PZG_ACC(slot, var)
+#define PZG_ACCW(slot, var)
 #endif
 
 namespace pzg {
@@ -163,6 +165,7 @@ struct BitReader {
     uint32_t mis_bits;     // 8 * (stream start - base)
     uint64_t end_rel;      // mis_bits + 8 * stream length: first bit (relative to base) past the stream
     uint64_t pos;          // next unread bit, relative to base
+    uint32_t win_end;      // a cursor in a dword below this index has >= 192 stream bits in front of it
 #if PZG_DEVICE_PASS
     uint32_t chunk0;       // dword index held by lane 0 of `cur` (multiple of 64)
     uint32_t cur, nxt;     // per-lane
@@ -174,13 +177,16 @@ struct BitReader {
     // Branch-free per lane (clamped index + select): a lane-dependent branch here would sit inside
     // the loops that carry the wave-uniform decoder state and make the compiler treat that state as
     // divergent (VALU + exec-mask loops instead of SALU + s_cbranch).
-    PZG_FN uint32_t load_chunk(uint32_t c0) const
+    PZG_FN uint32_t load_chunk(uint32_t c0) const { return zero_past_end(load_chunk_raw(c0), c0); }
+    // The load and the masking are separate so that `nxt` can stay an outstanding load (a prefetch):
+    // nothing waits for it until slide() promotes it to `cur`.
+    PZG_FN uint32_t load_chunk_raw(uint32_t c0) const
     {
         if (c0 >= ndw) return 0u;  // wave-uniform
         const uint32_t i = c0 + lane_id();
-        const uint32_t v = base[i < ndw ? i : ndw - 1u];
-        return i < ndw ? v : 0u;
+        return base[i < ndw ? i : ndw - 1u];
     }
+    PZG_FN uint32_t zero_past_end(uint32_t v, uint32_t c0) const { return c0 + lane_id() < ndw ? v : 0u; }
 
     PZG_FN void start(const uint8_t *in, uint64_t in_len, uint64_t byte_pos)
     {
@@ -192,10 +198,11 @@ struct BitReader {
         ndw = (uint32_t)((mis + remain + 3u) >> 2);
         end_rel = (uint64_t)mis_bits + remain * 8u;
         pos = mis_bits;
+        win_end = (end_rel >> 5) >= 6u ? (uint32_t)(end_rel >> 5) - 6u : 0u;
 #if PZG_DEVICE_PASS
         chunk0 = 0;
         cur = load_chunk(0u);
-        nxt = load_chunk(64u);
+        nxt = load_chunk_raw(64u);  // masked when it becomes `cur`
 #endif
     }
 
@@ -204,7 +211,7 @@ struct BitReader {
     {
 #if PZG_DEVICE_PASS
         const uint32_t a = read_lane(cur, i & 63u), b = read_lane(nxt, i & 63u);
-        return (i - chunk0) < 64u ? a : b;
+        return (i - chunk0) < 64u ? a : i < ndw ? b : 0u;
 #else
         return load_dw(i);
 #endif
@@ -215,14 +222,16 @@ struct BitReader {
     {
 #if PZG_DEVICE_PASS
         while ((uint32_t)(pos >> 5) - chunk0 >= 64u) {
-            cur = nxt;
             chunk0 += 64u;
-            nxt = load_chunk(chunk0 + 64u);
+            cur = zero_past_end(nxt, chunk0);
+            nxt = load_chunk_raw(chunk0 + 64u);
         }
 #endif
     }
 
     PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos; }
+    // cheap sufficient test for avail() >= 192 (7 whole dwords follow the cursor's dword index)
+    PZG_FN bool window_ok() const { return (uint32_t)(pos >> 5) < win_end; }
 
     // the next 32 bits (bits past the stream end read as whatever follows; callers check avail())
     PZG_FN uint32_t peek32() const
@@ -260,6 +269,15 @@ struct Decoder {
     uint32_t lit_n, dist_n;      // symbols of the current block's two codes: lens[0..lit_n) and lens[lit_n..lit_n+dist_n)
     int32_t status;
     uint32_t detail0, detail1;
+    // The last segment of a window is left pending: its bytes are gathered (LDS) and, for far sources,
+    // requested from HBM/L2, but selected and stored only when the next window has been decoded and
+    // walked, so the far-read latency overlaps that work instead of stalling the wave.
+    uint32_t pend_run;          // bytes of the pending segment (0 = none); they belong at op .. op+pend_run
+    uint32_t pend_far;          // nonzero: pendFV holds far bytes for the lanes flagged in pendBV bit 8
+    LaneVec<uint32_t> pendBV;   // [7:0] byte from the literal / near ring, [8] take the far byte instead
+    LaneVec<uint32_t> pendFV;   // far bytes (valid when pend_far)
+    uint32_t qn;                // tokens waiting in QT (lanes 0..qn-1), see window_append()
+    LaneVec<uint32_t> QT;
 #if defined(PZG_PROFILE)
     uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0 total, 1 header+tables, 2 token loop, 3 flush, 4 window_step, 5 checked steps, 6 windows, 7 matches
 #endif
@@ -277,6 +295,7 @@ struct Decoder {
         br.end_rel = uni64(br.end_rel);
         br.ndw = uni(br.ndw);
         br.mis_bits = uni(br.mis_bits);
+        br.win_end = uni(br.win_end);
         op = uni64(op);
         flushed = uni64(flushed);
         adler_a = uni(adler_a);
@@ -285,6 +304,9 @@ struct Decoder {
         dist_e15 = uni(dist_e15);
         lit_n = uni(lit_n);
         dist_n = uni(dist_n);
+        pend_run = uni(pend_run);
+        pend_far = uni(pend_far);
+        qn = uni(qn);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
 #endif
@@ -376,6 +398,22 @@ struct Decoder {
         flushed = to;
         wave_sync();
         PZG_ACC(3, tf);
+    }
+
+    // store the pending segment (see pend_run) and account for it
+    PZG_FN void complete_pending()
+    {
+        if (pend_run == 0u) return;
+        const uint32_t run = pend_run, op32 = (uint32_t)op;
+        const bool has_far = pend_far != 0u;
+        PZG_LANES_BEGIN(j)
+            const uint32_t bv = PZG_LV(pendBV, j);
+            const uint32_t v = (has_far && (bv & 0x100u)) ? PZG_LV(pendFV, j) : bv;
+            sel_store(j < run, &L.ring[(op32 + j) & RMASK], (uint8_t)v, j);
+        PZG_LANES_END
+        op += run;
+        pend_run = 0u;
+        maybe_flush();
     }
 
     PZG_FN void maybe_flush()
@@ -709,18 +747,27 @@ struct Decoder {
     }
 
     // ---- Deflate.hs:106-120 runInflate, wave-parallel ---------------------------------------------
+    // Three cooperating pieces:
+    //   window_append()  lane k decodes the token that would start k bits ahead of the cursor
+    //                    (literal/length lookup, length extra bits, distance lookup at its own offset,
+    //                    distance extra bits); a scalar walk visits the offsets that really are token
+    //                    starts; those tokens are compacted onto the tail of the wave's token queue.
+    //   emit_segment()   takes tokens worth <= 64 output bytes from the head of the queue and produces
+    //                    their bytes with one ring gather and one ring store.
+    //   token_loop()     keeps the queue deep enough that a segment is (nearly) always a full 64 bytes,
+    //                    and drains it before anything that is not a plain literal/match is decoded by
+    //                    token_step_checked() -- so errors surface in stream order, as in the reference.
+    // A queued token is one dword:  literal  LIT_FLAG | 1 << 16 | byte      match  len << 16 | dist.
+    static constexpr uint32_t LIT_FLAG = 0x80000000u;
+    static constexpr uint32_t QCAP = 63u;   // queue lanes 0..62; lane 63 receives what the compaction discards
+    static constexpr uint32_t QHIGH = 40u;  // emit when this many tokens wait (room for any ordinary window stays)
+
     // Precondition: at least WINDOW_MIN_BITS real bits follow the cursor, so every token that
-    // starts within the next 64 bits (at most 48 bits long) lies inside the stream.
-    // Lane k decodes the token that would start k bits ahead: literal/length lookup, length extra
-    // bits, distance lookup at its own offset, distance extra bits.  The scalar walk then visits
-    // the offsets that really are token starts.  Returns ST_OK after consuming >= 1 token or
-    // stopping in front of a token it leaves to token_step_checked(); an error status otherwise.
-    PZG_FN int window_step()
+    // starts within the next 64 bits (at most 48 bits long) lies inside the stream; qn < QCAP.
+    // Returns true when the token now at the cursor must go through token_step_checked().
+    PZG_FN bool window_append()
     {
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        const uint64_t tw0 = __builtin_amdgcn_s_memtime();
-#endif
-        // ---- phase A (all lanes): lane k decodes the token that would start k bits ahead ----------
+        // ---- phase A (all lanes) ---------------------------------------------------------------------
         const uint32_t i0 = (uint32_t)(br.pos >> 5), boff = (uint32_t)br.pos & 31u;
         uint32_t B0, B1, B2, B3, B4;
 #if PZG_DEVICE_PASS
@@ -740,9 +787,8 @@ struct Decoder {
             B3 = br.dword(i0 + 3u);
             B4 = br.dword(i0 + 4u);
         }
-        constexpr uint32_t LIT_FLAG = 0x80000000u, F_OTHER = 1u << 24, F_LIT = 1u << 25;
-        LaneVec<uint32_t> INFO;  // [7:0] token bits (64 for a token the walk must stop at)  [16:8] output bytes  [24] other  [25] literal
-        LaneVec<uint32_t> PV;    // literal: LIT_FLAG | byte    match: distance
+        LaneVec<uint32_t> TB;  // bits of the token at this offset; 64 = not a plain literal/match: the walk stops here
+        LaneVec<uint32_t> TK;  // the token, in queue format
         PZG_LANES_BEGIN(k)
             const uint32_t q = boff + k, sel = q >> 5, r = q & 31u;
             const uint32_t lo = sel == 0u ? B0 : sel == 1u ? B1 : B2;
@@ -759,16 +805,11 @@ struct Decoder {
             const uint32_t dist = ent_val(d) + ((w2 >> dn) & ((1u << dex) - 1u));
             const bool is_lit = kind == K_LIT;
             const bool is_match = kind == K_BASE && ent_kind(d) == K_BASE;
-            const uint32_t tb = is_lit ? n : is_match ? o + dn + dex : 64u;
-            const uint32_t lout = is_lit ? 1u : is_match ? lenv : 0u;
-            PZG_LV(INFO, k) = tb | (lout << 8) | (is_lit ? F_LIT : is_match ? 0u : F_OTHER);
-            PZG_LV(PV, k) = is_lit ? (LIT_FLAG | (lenv & 0xffu)) : is_match ? dist : 0u;
+            PZG_LV(TB, k) = is_lit ? n : is_match ? o + dn + dex : 64u;
+            PZG_LV(TK, k) = is_lit ? (LIT_FLAG | (1u << 16) | (lenv & 0xffu)) : is_match ? ((lenv << 16) | dist) : 0u;
         PZG_LANES_END
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
         prof[6] += 1;
-        __builtin_amdgcn_s_waitcnt(0);
-        prof[8] += __builtin_amdgcn_s_memtime() - tw0;
-        const uint64_t tw1 = __builtin_amdgcn_s_memtime();
 #endif
         // ---- phase B (scalar): follow the real chain; S = offsets that are token starts ---------------
         // The only serial part: one v_readlane and four SALU ops per token, no LDS, no lane work.
@@ -780,138 +821,175 @@ struct Decoder {
 #else
             S |= 1ull << kend;
 #endif
-            kend += lane_get(INFO, kend) & 0xffu;
+            kend += lane_get(TB, kend);
         } while (kend < 64u);
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        prof[7] += popc64(S);
-        prof[9] += __builtin_amdgcn_s_memtime() - tw1;
-        const uint64_t te0 = __builtin_amdgcn_s_memtime();
-#endif
-        // ---- phase C (all lanes): place and produce the bytes of all those tokens at once -------------
-        // A segment is at most 64 output bytes.  Token lanes learn their output offset from a prefix
-        // sum of their lengths, drop their lane id into a marker at that offset, and a prefix maximum
-        // tells every output lane which token it belongs to; one ring gather + one ring store follow.
-        // A token ends the segment (and is retried as the head of the next one) if it is not a plain
-        // literal/match, does not fit the 64 lanes, or is a match whose source is not complete before
-        // the segment starts (dist < offset + len) or lies before the output (dist > produced + offset).
-        uint64_t Srem = S;
-        uint32_t consumed = kend;
-        int rc = ST_OK;
-        while (Srem != 0) {
-            const uint32_t hist = op > 0x100000u ? 0x100000u : (uint32_t)op;  // dist <= 32768: a clamp is enough
-            const uint32_t op32 = (uint32_t)op;
-            LaneVec<uint32_t> INCL, STOP;
+        // the chain's last token is the only one that can be a stopper (it ends the walk)
+        LaneVec<uint32_t> ST;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(ST, k) = PZG_LV(TB, k) == 64u ? 1u : 0u;
+        PZG_LANES_END
+        const uint64_t stopbit = S & lanes_ballot(ST);
+        bool stopper = stopbit != 0;
+        uint32_t consumed = stopper ? kend - 64u : kend;
+        uint64_t tokens = S & ~stopbit;
+        // ---- compaction: token lanes go to the queue's tail, in order ---------------------------------
+        const uint32_t room = QCAP - qn;
+        uint32_t nt = popc64(tokens);
+        if (nt > room) {  // (a window of very short codes) take what fits, the rest is decoded again
+            LaneVec<uint32_t> FIRST_OUT;
             PZG_LANES_BEGIN(k)
-                PZG_LV(INCL, k) = ((Srem >> k) & 1ull) ? ((PZG_LV(INFO, k) >> 8) & 511u) : 0u;
+                PZG_LV(FIRST_OUT, k) = (((tokens >> k) & 1ull) && mbcnt_k(tokens, k) == room) ? 1u : 0u;
             PZG_LANES_END
-            lanes_iscan_add(INCL);
-            PZG_LANES_BEGIN(k)
-                const uint32_t inf = PZG_LV(INFO, k), lout = (inf >> 8) & 511u, pv = PZG_LV(PV, k);
-                const uint32_t endb = PZG_LV(INCL, k), start = endb - (((Srem >> k) & 1ull) ? lout : 0u);
-                const bool is_match = (inf & (F_OTHER | F_LIT)) == 0u;
-                const bool bad = (inf & F_OTHER) != 0u || endb > 64u || (is_match && (pv < endb || pv > hist + start));
-                PZG_LV(STOP, k) = (((Srem >> k) & 1ull) && bad) ? 1u : 0u;
-            PZG_LANES_END
-            const uint64_t stopmask = lanes_ballot(STOP);
-            const uint32_t v = stopmask ? ctz64(stopmask) : 64u;
-            const uint32_t vinf = lane_get(INFO, v & 63u);
-            // bytes of the tokens below v
-            const uint32_t run = v < 64u ? lane_get(INCL, v) - ((vinf >> 8) & 511u) : lane_get(INCL, 63u);
-            if (run != 0u) {
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-                prof[13] += 1;
-#endif
-                const uint64_t emit = Srem & (v < 64u ? ((1ull << v) - 1ull) : ~0ull);
-                LaneVec<uint32_t> TOK, PJ;
-                PZG_LANES_BEGIN(k)
-                    const uint32_t lout = (PZG_LV(INFO, k) >> 8) & 511u;
-                    sel_store(((emit >> k) & 1ull) != 0, &L.mk[(PZG_LV(INCL, k) - lout) & 63u], (uint8_t)(k + 1u), k);
-                PZG_LANES_END
-                PZG_LANES_BEGIN(j)
-                    PZG_LV(TOK, j) = L.mk[j];
-                PZG_LANES_END
-                PZG_LANES_BEGIN(j)
-                    L.mk[j] = 0;  // leave the marker clean for the next segment
-                PZG_LANES_END
-                lanes_iscan_max(TOK);
-                PZG_LANES_BEGIN(j)
-                    PZG_LV(TOK, j) = (PZG_LV(TOK, j) - 1u) & 63u;
-                PZG_LANES_END
-                lanes_gather(PJ, PV, TOK);
-                LaneVec<uint32_t> BV;
-                PZG_LANES_BEGIN(j)
-                    const uint32_t pj = PZG_LV(PJ, j);
-                    const uint8_t g = L.ring[(op32 + j - pj) & RMASK];
-                    PZG_LV(BV, j) = (pj & LIT_FLAG) ? (pj & 0xffu) : g;
-                PZG_LANES_END
-                if (HYBRID) {  // sources older than the ring: the stream's own flushed output
-                    LaneVec<uint32_t> FAR;
-                    PZG_LANES_BEGIN(j)
-                        const uint32_t pj = PZG_LV(PJ, j);
-                        PZG_LV(FAR, j) = (j < run && (pj & LIT_FLAG) == 0u && pj - j > RING) ? 1u : 0u;
-                    PZG_LANES_END
-                    if (lanes_ballot(FAR)) {
-                        far_fence();
-                        PZG_LANES_BEGIN(j)
-                            const bool far = PZG_LV(FAR, j) != 0u;
-                            const uint8_t fv = fetch_far(far, PZG_LV(PJ, j) - j);
-                            PZG_LV(BV, j) = far ? fv : PZG_LV(BV, j);
-                        PZG_LANES_END
-                    }
-                }
-                PZG_LANES_BEGIN(j)
-                    sel_store(j < run, &L.ring[(op32 + j) & RMASK], (uint8_t)PZG_LV(BV, j), j);
-                PZG_LANES_END
-                op += run;
-                maybe_flush();
-            }
-            if (v >= 64u) break;  // every token of the window is out
-            // token at offset v ended the segment
-            if (vinf & F_OTHER) {
-                consumed = v;  // end of block, long code or error: the checked path takes it from here
-                break;
-            }
-            Srem &= ~((1ull << v) - 1ull);
-            if ((vinf & F_LIT) == 0u) {
-                const uint32_t dist = lane_get(PV, v);
-                if ((uint64_t)dist > op) {  // (`run` bytes were just added to op)
-                    rc = fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
-                    consumed = v;
-                    break;
-                }
-                if (run == 0u) {  // heads the segment and still does not fit: overlapping or longer than a wave
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-                    prof[14] += 1;
-#endif
-                    copy_match(dist, (vinf >> 8) & 511u);
-                    maybe_flush();
-                    Srem &= ~(1ull << v);
-                }
-            }
+            consumed = ctz64(lanes_ballot(FIRST_OUT));
+            tokens &= (1ull << consumed) - 1ull;
+            nt = room;
+            stopper = false;
         }
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        __builtin_amdgcn_s_waitcnt(0);
-        prof[12] += __builtin_amdgcn_s_memtime() - te0;
-        const uint64_t tw2 = __builtin_amdgcn_s_memtime();
+        prof[7] += nt;
 #endif
+        LaneVec<uint32_t> DEST, RECV;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(DEST, k) = ((tokens >> k) & 1ull) ? qn + mbcnt_k(tokens, k) : 63u;
+        PZG_LANES_END
+        lanes_scatter(RECV, TK, DEST);
+        PZG_LANES_BEGIN(j)
+            PZG_LV(QT, j) = (j >= qn && j < qn + nt) ? PZG_LV(RECV, j) : PZG_LV(QT, j);
+        PZG_LANES_END
+        qn += nt;
         br.drop(consumed);
+        return stopper;
+    }
+
+    // Place and produce the bytes of the queue's leading tokens.  A segment is at most 64 output
+    // bytes.  Token lanes learn their output offset from a prefix sum of their lengths, drop their
+    // lane id into a marker at that offset, and a prefix maximum tells every output lane which token
+    // it belongs to; one ring gather (+ one far gather) and one ring store follow.  A token ends the
+    // segment (and heads the next one) if it does not fit the 64 lanes or is a match whose source is
+    // not complete before the segment starts (dist < offset + len) or lies before the output
+    // (dist > produced + offset).  A match that heads a segment and still does not fit overlaps its own
+    // output or is longer than a wave: copy_match() takes it.  Precondition: qn != 0.
+    PZG_FN int emit_segment()
+    {
+        PZG_T0(t_a);
+        complete_pending();  // the previous segment's bytes must be in the ring (and in `op`) from here on
+        PZG_ACCW(8, t_a);
+        PZG_T0(t_b);
+        const uint32_t hist = op > 0x100000u ? 0x100000u : (uint32_t)op;  // dist <= 32768: a clamp is enough
+        const uint32_t op32 = (uint32_t)op;
+        LaneVec<uint32_t> INCL, STOP;
+        PZG_LANES_BEGIN(t)
+            PZG_LV(INCL, t) = t < qn ? ((PZG_LV(QT, t) >> 16) & 511u) : 0u;
+        PZG_LANES_END
+        lanes_iscan_add(INCL);
+        PZG_LANES_BEGIN(t)
+            const uint32_t tk = PZG_LV(QT, t), lout = (tk >> 16) & 511u, dist = tk & 0xffffu;
+            const uint32_t endb = PZG_LV(INCL, t), start = endb - lout;
+            const bool is_match = (tk & LIT_FLAG) == 0u;
+            PZG_LV(STOP, t) = (t < qn && (endb > 64u || (is_match && (dist < endb || dist > hist + start)))) ? 1u : 0u;
+        PZG_LANES_END
+        const uint64_t stopmask = lanes_ballot(STOP);
+        uint32_t v = stopmask ? ctz64(stopmask) : qn;  // tokens of this segment
+        PZG_ACCW(9, t_b);
+        PZG_T0(t_c);
+        if (v == 0u) {
+            const uint32_t tk = lane_get(QT, 0u), dist = tk & 0xffffu, len = (tk >> 16) & 511u;
+            if ((uint64_t)dist > op) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        prof[11] += __builtin_amdgcn_s_memtime() - tw2;
+            prof[14] += 1;
 #endif
-        return rc;
+            copy_match(dist, len);
+            maybe_flush();
+            v = 1u;
+        } else {
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+            prof[13] += 1;
+#endif
+            const uint32_t run = lane_get(INCL, v - 1u);
+            LaneVec<uint32_t> TOK, PJ;
+            PZG_LANES_BEGIN(t)
+                const uint32_t lout = (PZG_LV(QT, t) >> 16) & 511u;
+                sel_store(t < v, &L.mk[(PZG_LV(INCL, t) - lout) & 63u], (uint8_t)(t + 1u), t);
+            PZG_LANES_END
+            PZG_LANES_BEGIN(j)
+                PZG_LV(TOK, j) = L.mk[j];
+            PZG_LANES_END
+            PZG_LANES_BEGIN(j)
+                L.mk[j] = 0;  // leave the marker clean for the next segment
+            PZG_LANES_END
+            lanes_iscan_max(TOK);
+            PZG_LANES_BEGIN(j)
+                PZG_LV(TOK, j) = (PZG_LV(TOK, j) - 1u) & 63u;
+            PZG_LANES_END
+            lanes_gather(PJ, QT, TOK);
+            LaneVec<uint32_t> BV;
+            PZG_LANES_BEGIN(j)
+                const uint32_t pj = PZG_LV(PJ, j);
+                const uint8_t g = L.ring[(op32 + j - (pj & 0xffffu)) & RMASK];
+                PZG_LV(BV, j) = (pj & LIT_FLAG) ? (pj & 0xffu) : g;
+            PZG_LANES_END
+            pend_far = 0u;
+            PZG_ACCW(10, t_c);
+            PZG_T0(t_d);
+            if (HYBRID) {  // sources older than the ring: the stream's own flushed output
+                LaneVec<uint32_t> FAR;
+                PZG_LANES_BEGIN(j)
+                    const uint32_t pj = PZG_LV(PJ, j);
+                    PZG_LV(FAR, j) = (j < run && (pj & LIT_FLAG) == 0u && (pj & 0xffffu) - j > RING) ? 1u : 0u;
+                PZG_LANES_END
+                if (lanes_ballot(FAR)) {
+                    far_fence();
+                    pend_far = 1u;
+                    PZG_LANES_BEGIN(j)
+                        const bool far = PZG_LV(FAR, j) != 0u;
+                        PZG_LV(pendFV, j) = fetch_far(far, (PZG_LV(PJ, j) & 0xffffu) - j);  // issued now, waited for in complete_pending()
+                        PZG_LV(BV, j) = (PZG_LV(BV, j) & 0xffu) | (far ? 0x100u : 0u);
+                    PZG_LANES_END
+                }
+            }
+            PZG_LANES_BEGIN(j)
+                PZG_LV(pendBV, j) = PZG_LV(BV, j);
+            PZG_LANES_END
+            pend_run = run;  // stored by complete_pending(): next segment, or on the way out
+            PZG_ACC(11, t_d);
+        }
+        // the queue moves up by v tokens
+        LaneVec<uint32_t> SRC;
+        PZG_LANES_BEGIN(j)
+            PZG_LV(SRC, j) = j + v;
+        PZG_LANES_END
+        lanes_gather(QT, QT, SRC);
+        qn -= v;
+        return ST_OK;
     }
 
     PZG_FN int token_loop()
     {
         for (;;) {
-            if (br.avail() >= WINDOW_MIN_BITS) {
-                const uint64_t before = br.pos;
-                PZG_T0(tw);
-                const int stw = window_step();
-                PZG_ACC(4, tw);
-                if (stw) return stw;
-                if (br.pos != before) continue;  // else: the very next token needs the checked path
+            // fill: decode windows until the queue is deep or the token at the cursor needs the checked path
+            bool stopper = false;
+            PZG_T0(tw);
+            while (qn < QHIGH) {
+                if (!br.window_ok() || window_append()) {
+                    stopper = true;
+                    break;
+                }
             }
+            PZG_ACC(4, tw);
+            PZG_T0(te);
+            if (!stopper) {
+                const int se = emit_segment();
+                PZG_ACC(12, te);
+                if (se) return se;
+                continue;
+            }
+            // drain, so that whatever the checked step reports comes after everything before it
+            while (qn != 0u) {
+                const int se = emit_segment();
+                if (se) return se;
+            }
+            complete_pending();
+            PZG_ACC(12, te);
             PZG_T0(tc);
             const int st = token_step_checked();
             PZG_ACC(5, tc);
@@ -1071,6 +1149,8 @@ struct Decoder {
         adler_b = 0;
         lit_e15 = dist_e15 = 0;
         lit_n = dist_n = 0;
+        pend_run = pend_far = 0;
+        qn = 0;
         status = ST_OK;
         detail0 = detail1 = 0;
         in_byte0 = 0;

@@ -254,6 +254,20 @@ PZG_FN void lanes_gather(LaneVec<uint32_t> &out, const LaneVec<uint32_t> &src, c
 #endif
 }
 
+// out[dst[k] & 63] = src[k]  (ds_permute_b32: a scatter through the LDS crossbar); lanes nobody
+// sends to receive 0.  Callers send colliding lanes only to a lane whose result they ignore.
+PZG_FN void lanes_scatter(LaneVec<uint32_t> &out, const LaneVec<uint32_t> &src, const LaneVec<uint32_t> &dst)
+{
+#if PZG_DEVICE_PASS
+    out.v = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst.v << 2), (int)src.v);
+#else
+    LaneVec<uint32_t> tmp;
+    for (uint32_t k = 0; k < 64u; ++k) tmp.v[k] = 0u;
+    for (uint32_t k = 0; k < 64u; ++k) tmp.v[dst.v[k] & 63u] = src.v[k];
+    out = tmp;
+#endif
+}
+
 // mask of lanes whose predicate is set (the LaneVec holds 0/1)
 PZG_FN uint64_t lanes_ballot(const LaneVec<uint32_t> &p)
 {

@@ -33,10 +33,12 @@ prof = np.zeros((nstreams, 16), np.uint64)
 L.pzg_prof_buffer(ctx.handle, nstreams, prof.ctypes.data)
 m = prof.astype(np.float64).mean(axis=0)
 print(f"streams {nstreams} x {size} B; kernel {ms:.3f} ms; status ok {int((status==0).sum())}; outputs ok {all(out_buf[int(out_off[k]):int(out_off[k])+size].tobytes()==datas[k%64] for k in range(min(nstreams,64)))}")
-names = ["total", "header+tables", "token loop", "flush+adler", "window_step", "checked steps", "#windows", "#tokens in windows",
-         "  win: lookups", "  win: walk+emit", "#matches", "  win: drop/slide", "  win: emission", "#segments", "#general copies", "-"]
+names = ["total", "header+tables", "token loop", "flush+adler", "window_append", "checked steps", "#windows", "#tokens queued",
+         "  emit: complete_pending", "  emit: scan+stop", "  emit: marker+gather", "  emit: far", "emit_segment", "#segments", "#general copies", "-"]
 for i, nme in enumerate(names):
+    if nme == "-":
+        continue
     extra = f"({100*m[i]/m[0]:5.1f}%)" if not nme.startswith("#") else ""
     print(f"  {nme:22s} {m[i]:12.0f} {extra}")
-print(f"  emission cycles/segment {m[12]/max(m[13],1):.0f}; gather cycles/token {(m[9]-m[12])/max(m[7],1):.0f}")
-print(f"  cycles/window {m[4]/max(m[6],1):.0f}; tokens/window {m[7]/max(m[6],1):.2f}; cycles/token {m[4]/max(m[7],1):.0f}; lookups/window {m[8]/max(m[6],1):.0f}; walk/window {m[9]/max(m[6],1):.0f}")
+print(f"  cycles/window {m[4]/max(m[6],1):.0f}; tokens/window {m[7]/max(m[6],1):.2f}; cycles/segment {m[12]/max(m[13]+m[14],1):.0f}; "
+      f"bytes/segment {size/max(m[13],1):.1f}; tokens/segment {m[7]/max(m[13]+m[14],1):.2f}; windows/segment {m[6]/max(m[13],1):.2f}")
