@@ -139,7 +139,6 @@ struct alignas(16) WaveLds {
     uint32_t cnt[16];                    // histogram / running-rank scratch for build_table
     uint8_t lens[MAX_LENS + 22];         // code lengths of the block being set up
     uint8_t cl_lens[20];                 // code-length code lengths in symbol order
-    uint8_t mk[64];                      // window_step's byte->token marker; all zero between segments
     uint32_t fixed_ready;                // 0x51DF1BED while lit/dist tables hold the fixed code: survives from one stream to the
                                          // next on a persistent wave, so a batch of fixed-Huffman streams builds it once per wave
     uint8_t dump[64 + 12];               // where masked-off lanes store (see sel_store): keeps hot loops free of lane-dependent branches
@@ -768,32 +767,33 @@ struct Decoder {
     PZG_FN bool window_append()
     {
         // ---- phase A (all lanes) ---------------------------------------------------------------------
+        // lane k needs the three dwords that hold stream bits [k, k+96) from the cursor
         const uint32_t i0 = (uint32_t)(br.pos >> 5), boff = (uint32_t)br.pos & 31u;
-        uint32_t B0, B1, B2, B3, B4;
+        LaneVec<uint32_t> LO, MID, HI;
 #if PZG_DEVICE_PASS
         const uint32_t li = i0 - br.chunk0;  // < 64 (slide() keeps the cursor's dword inside `cur`)
-        if (li <= 59u) {                     // all five dwords sit in the current chunk register
-            B0 = read_lane(br.cur, li);
-            B1 = read_lane(br.cur, li + 1u);
-            B2 = read_lane(br.cur, li + 2u);
-            B3 = read_lane(br.cur, li + 3u);
-            B4 = read_lane(br.cur, li + 4u);
+        if (li <= 59u) {                     // all five dwords sit in the current chunk register: three crossbar gathers
+            const uint32_t a = (li + ((boff + lane_id()) >> 5)) << 2;
+            LO.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
+            MID.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
+            HI.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
         } else
 #endif
         {
-            B0 = br.dword(i0);
-            B1 = br.dword(i0 + 1u);
-            B2 = br.dword(i0 + 2u);
-            B3 = br.dword(i0 + 3u);
-            B4 = br.dword(i0 + 4u);
+            const uint32_t B0 = br.dword(i0), B1 = br.dword(i0 + 1u), B2 = br.dword(i0 + 2u), B3 = br.dword(i0 + 3u),
+                           B4 = br.dword(i0 + 4u);
+            PZG_LANES_BEGIN(k)
+                const uint32_t sel = (boff + k) >> 5;
+                PZG_LV(LO, k) = sel == 0u ? B0 : sel == 1u ? B1 : B2;
+                PZG_LV(MID, k) = sel == 0u ? B1 : sel == 1u ? B2 : B3;
+                PZG_LV(HI, k) = sel == 0u ? B2 : sel == 1u ? B3 : B4;
+            PZG_LANES_END
         }
         LaneVec<uint32_t> TB;  // bits of the token at this offset; 64 = not a plain literal/match: the walk stops here
         LaneVec<uint32_t> TK;  // the token, in queue format
         PZG_LANES_BEGIN(k)
-            const uint32_t q = boff + k, sel = q >> 5, r = q & 31u;
-            const uint32_t lo = sel == 0u ? B0 : sel == 1u ? B1 : B2;
-            const uint32_t mid = sel == 0u ? B1 : sel == 1u ? B2 : B3;
-            const uint32_t hi = sel == 0u ? B2 : sel == 1u ? B3 : B4;
+            const uint32_t r = (boff + k) & 31u;
+            const uint32_t lo = PZG_LV(LO, k), mid = PZG_LV(MID, k), hi = PZG_LV(HI, k);
             const uint32_t w_lo = funnel(mid, lo, r), w_hi = funnel(hi, mid, r);  // stream bits [k, k+64)
             const uint32_t e = L.lit_lut[w_lo & ((1u << LIT_BITS) - 1u)];
             const uint32_t n = ent_n(e), ex = ent_e(e), kind = ent_kind(e);
@@ -906,20 +906,20 @@ struct Decoder {
             prof[13] += 1;
 #endif
             const uint32_t run = lane_get(INCL, v - 1u);
-            LaneVec<uint32_t> TOK, PJ;
+            // Which token does output byte j belong to?  Token t announces itself at lane START[t] (one
+            // crossbar scatter); the tokens sit in the queue in output order, so byte j belongs to token
+            // (number of announcements at lanes <= j) - 1.  Lanes that send nothing real repeat token 0's
+            // announcement at lane 0, so colliding writes all carry the same value.
+            LaneVec<uint32_t> TOK, PJ, ONE, DEST, MARK;
             PZG_LANES_BEGIN(t)
                 const uint32_t lout = (PZG_LV(QT, t) >> 16) & 511u;
-                sel_store(t < v, &L.mk[(PZG_LV(INCL, t) - lout) & 63u], (uint8_t)(t + 1u), t);
+                PZG_LV(DEST, t) = t < v ? PZG_LV(INCL, t) - lout : 0u;
+                PZG_LV(ONE, t) = 1u;
             PZG_LANES_END
+            lanes_scatter(MARK, ONE, DEST);
+            const uint64_t starts = lanes_ballot(MARK);
             PZG_LANES_BEGIN(j)
-                PZG_LV(TOK, j) = L.mk[j];
-            PZG_LANES_END
-            PZG_LANES_BEGIN(j)
-                L.mk[j] = 0;  // leave the marker clean for the next segment
-            PZG_LANES_END
-            lanes_iscan_max(TOK);
-            PZG_LANES_BEGIN(j)
-                PZG_LV(TOK, j) = (PZG_LV(TOK, j) - 1u) & 63u;
+                PZG_LV(TOK, j) = (mbcnt_k(starts, j) + (uint32_t)((starts >> j) & 1ull) - 1u) & 63u;
             PZG_LANES_END
             lanes_gather(PJ, QT, TOK);
             LaneVec<uint32_t> BV;
@@ -993,6 +993,9 @@ struct Decoder {
             PZG_T0(tc);
             const int st = token_step_checked();
             PZG_ACC(5, tc);
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+            prof[15] += 1;
+#endif
             if (st == STEP_EOB) return ST_OK;
             if (st != ST_OK) return st;
         }
@@ -1154,8 +1157,6 @@ struct Decoder {
         status = ST_OK;
         detail0 = detail1 = 0;
         in_byte0 = 0;
-        for (uint32_t i0 = 0; i0 < 64u; i0 += PZG_WAVE) L.mk[(i0 + lane_id()) & 63u] = 0;
-        wave_sync();
         br.start(in, in_len, 0);
         PZG_T0(tall);
         decode();
