@@ -231,6 +231,16 @@ struct BitReader {
     PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos; }
     // cheap sufficient test for avail() >= 192 (7 whole dwords follow the cursor's dword index)
     PZG_FN bool window_ok() const { return (uint32_t)(pos >> 5) < win_end; }
+    // same for a 128-bit window (10 whole dwords follow), and on the device its eight dwords sit in `cur`
+    PZG_FN bool window2_ok() const
+    {
+        const uint32_t i = (uint32_t)(pos >> 5);
+#if PZG_DEVICE_PASS
+        return i + 3u < win_end && i - chunk0 <= 56u;
+#else
+        return i + 3u < win_end;
+#endif
+    }
 
     // the next 32 bits (bits past the stream end read as whatever follows; callers check avail())
     PZG_FN uint32_t peek32() const
@@ -242,6 +252,19 @@ struct BitReader {
     {
         pos += n;
         slide();
+    }
+    // drop() for n < 2048 from a cursor slide() has already placed: at most one chunk step, written
+    // without a loop so the prefetch into `nxt` stays an outstanding load (no copy of it is needed).
+    PZG_FN void drop_short(uint32_t n)
+    {
+        pos += n;
+#if PZG_DEVICE_PASS
+        if ((uint32_t)(pos >> 5) - chunk0 >= 64u) {
+            chunk0 += 64u;
+            cur = zero_past_end(nxt, chunk0);
+            nxt = load_chunk_raw(chunk0 + 64u);
+        }
+#endif
     }
     PZG_FN void align_to_byte() { drop((uint32_t)(8u - ((uint32_t)pos & 7u)) & 7u); }
 };
@@ -639,9 +662,13 @@ struct Decoder {
     template <int TREE>
     PZG_FN uint32_t decode_long(uint32_t bits, const TreeMeta *meta, const uint8_t *lens, uint32_t nsym, uint32_t e15)
     {
-        uint32_t code = 0;
+        // The primary table sent us here (K_LONG), so no code of length <= P matches and the P-bit prefix
+        // is below the end of all codes: the walk resumes at depth P + 1.
+        constexpr uint32_t P = TREE == TREE_LITLEN ? (uint32_t)LIT_BITS : (uint32_t)DIST_BITS;
+        uint32_t code = bitrev32(bits) >> (32u - P);
+        bits >>= P;
 #pragma nounroll
-        for (uint32_t l = 1; l < 16u; ++l) {
+        for (uint32_t l = P + 1u; l < 16u; ++l) {
             code = (code << 1) | (bits & 1u);
             bits >>= 1;
             const uint32_t cnt_l = uni(meta->count[l]);
@@ -688,9 +715,24 @@ struct Decoder {
         return ST_OK;
     }
 
+    // ---- the wave's token queue (see window_append / emit_segment below) ---------------------------
+    // A queued token is one dword:  literal  LIT_FLAG | 1 << 16 | byte      match  len << 16 | dist.
+    static constexpr uint32_t LIT_FLAG = 0x80000000u;
+    static constexpr uint32_t QCAP = 63u;   // queue lanes 0..62; lane 63 receives what the compaction discards
+    static constexpr uint32_t QHIGH = 40u;  // emit when this many tokens wait (room for any ordinary window stays)
+
+    PZG_FN void queue_push(uint32_t tk)  // qn < QCAP
+    {
+        PZG_LANES_BEGIN(j)
+            PZG_LV(QT, j) = j == qn ? tk : PZG_LV(QT, j);
+        PZG_LANES_END
+        qn += 1u;
+    }
+
     // ---- Deflate.hs:106-120 runInflate: one token, every bit checked against the stream end ------
-    // Used near the end of the stream and for whatever window_step() does not handle itself
-    // (end-of-block, codes longer than the primary tables, every error).
+    // Used near the end of the stream and for whatever window_append() does not handle itself
+    // (end-of-block, codes longer than the primary tables, every error).  A literal or match is put
+    // on the token queue like the windows' tokens.
     // Returns ST_OK (token consumed), 1000 (end of block consumed) or an error status.
     static constexpr int STEP_EOB = 1000;
     PZG_FN int token_step_checked()
@@ -706,8 +748,7 @@ struct Decoder {
             const uint32_t n = ent_n(e);
             if (br.avail() < (int64_t)n) return fail(ST_TRUNCATED, 0, 0);
             br.drop(n);
-            put_literal(ent_val(e));
-            maybe_flush();
+            queue_push(LIT_FLAG | (1u << 16) | (ent_val(e) & 0xffu));
             return ST_OK;
         }
         if (kind == K_BASE) {
@@ -731,9 +772,7 @@ struct Decoder {
             if (br.avail() < (int64_t)(dn + dex)) return fail(ST_TRUNCATED, 0, 0);
             const uint32_t dist = ent_val(d) + ((bits >> dn) & ((1u << dex) - 1u));
             br.drop(dn + dex);
-            if ((uint64_t)dist > op) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
-            copy_match(dist, len);
-            maybe_flush();
+            queue_push((len << 16) | dist);  // emit_segment() checks the distance against what has been produced by then
             return ST_OK;
         }
         if (int st = check_entry(e)) return st;
@@ -753,13 +792,29 @@ struct Decoder {
     //                    starts; those tokens are compacted onto the tail of the wave's token queue.
     //   emit_segment()   takes tokens worth <= 64 output bytes from the head of the queue and produces
     //                    their bytes with one ring gather and one ring store.
-    //   token_loop()     keeps the queue deep enough that a segment is (nearly) always a full 64 bytes,
-    //                    and drains it before anything that is not a plain literal/match is decoded by
-    //                    token_step_checked() -- so errors surface in stream order, as in the reference.
-    // A queued token is one dword:  literal  LIT_FLAG | 1 << 16 | byte      match  len << 16 | dist.
-    static constexpr uint32_t LIT_FLAG = 0x80000000u;
-    static constexpr uint32_t QCAP = 63u;   // queue lanes 0..62; lane 63 receives what the compaction discards
-    static constexpr uint32_t QHIGH = 40u;  // emit when this many tokens wait (room for any ordinary window stays)
+    //   token_loop()     keeps the queue deep enough that a segment is (nearly) always a full 64 bytes.
+    //                    token_step_checked() decodes what a window cannot (long codes, the stream's last
+    //                    bits) onto the same queue; at an end of block or an error the queue is drained
+    //                    first, so errors surface in stream order, as in the reference.
+
+    // One lane's speculative decode: the token whose first bit is bit r of (hi:mid:lo).
+    // tb = its length in bits, 64 if it is not a plain literal/match (the walk stops there); tk = the token.
+    PZG_FN void decode_at(uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r, uint32_t &tb, uint32_t &tk)
+    {
+        const uint32_t w_lo = funnel(mid, lo, r), w_hi = funnel(hi, mid, r);   // 64 stream bits from the token's first
+        const uint32_t e = L.lit_lut[w_lo & ((1u << LIT_BITS) - 1u)];
+        const uint32_t n = ent_n(e), ex = ent_e(e), kind = ent_kind(e);
+        const uint32_t o = n + ex;                                             // <= 20
+        const uint32_t lenv = ent_val(e) + ((w_lo >> n) & ((1u << ex) - 1u));  // literal byte when kind == K_LIT
+        const uint32_t w2 = funnel(w_hi, w_lo, o);                             // bits after the length code
+        const uint32_t d = L.dist_lut[w2 & ((1u << DIST_BITS) - 1u)];
+        const uint32_t dn = ent_n(d), dex = ent_e(d);                          // dn + dex <= 28
+        const uint32_t dist = ent_val(d) + ((w2 >> dn) & ((1u << dex) - 1u));
+        const bool is_lit = kind == K_LIT;
+        const bool is_match = kind == K_BASE && ent_kind(d) == K_BASE;
+        tb = is_lit ? n : is_match ? o + dn + dex : 64u;
+        tk = is_lit ? (LIT_FLAG | (1u << 16) | (lenv & 0xffu)) : is_match ? ((lenv << 16) | dist) : 0u;
+    }
 
     // Precondition: at least WINDOW_MIN_BITS real bits follow the cursor, so every token that
     // starts within the next 64 bits (at most 48 bits long) lies inside the stream; qn < QCAP.
@@ -794,19 +849,7 @@ struct Decoder {
         PZG_LANES_BEGIN(k)
             const uint32_t r = (boff + k) & 31u;
             const uint32_t lo = PZG_LV(LO, k), mid = PZG_LV(MID, k), hi = PZG_LV(HI, k);
-            const uint32_t w_lo = funnel(mid, lo, r), w_hi = funnel(hi, mid, r);  // stream bits [k, k+64)
-            const uint32_t e = L.lit_lut[w_lo & ((1u << LIT_BITS) - 1u)];
-            const uint32_t n = ent_n(e), ex = ent_e(e), kind = ent_kind(e);
-            const uint32_t o = n + ex;                                             // <= 20
-            const uint32_t lenv = ent_val(e) + ((w_lo >> n) & ((1u << ex) - 1u));  // literal byte when kind == K_LIT
-            const uint32_t w2 = funnel(w_hi, w_lo, o);                             // bits after the length code
-            const uint32_t d = L.dist_lut[w2 & ((1u << DIST_BITS) - 1u)];
-            const uint32_t dn = ent_n(d), dex = ent_e(d);                          // dn + dex <= 28
-            const uint32_t dist = ent_val(d) + ((w2 >> dn) & ((1u << dex) - 1u));
-            const bool is_lit = kind == K_LIT;
-            const bool is_match = kind == K_BASE && ent_kind(d) == K_BASE;
-            PZG_LV(TB, k) = is_lit ? n : is_match ? o + dn + dex : 64u;
-            PZG_LV(TK, k) = is_lit ? (LIT_FLAG | (1u << 16) | (lenv & 0xffu)) : is_match ? ((lenv << 16) | dist) : 0u;
+            decode_at(lo, mid, hi, r, PZG_LV(TB, k), PZG_LV(TK, k));
         PZG_LANES_END
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
         prof[6] += 1;
@@ -857,7 +900,116 @@ struct Decoder {
             PZG_LV(QT, j) = (j >= qn && j < qn + nt) ? PZG_LV(RECV, j) : PZG_LV(QT, j);
         PZG_LANES_END
         qn += nt;
-        br.drop(consumed);
+        br.drop_short(consumed);
+        return stopper;
+    }
+
+    // window_append() over 128 bits: lane k decodes at offsets k and k + 64.  The two decodes are
+    // independent, so their LDS round trips overlap, and the per-window bookkeeping is paid once.
+    // Precondition: br.window2_ok(); qn < QCAP.  Falls back to the first half alone when the queue
+    // cannot take both.
+    PZG_FN bool window_append2()
+    {
+        const uint32_t i0 = (uint32_t)(br.pos >> 5), boff = (uint32_t)br.pos & 31u;
+        LaneVec<uint32_t> TB0, TK0, TB1, TK1;
+#if PZG_DEVICE_PASS
+        {
+            const uint32_t li = i0 - br.chunk0;  // <= 56 (window2_ok): dwords li .. li + 7 sit in `cur`
+            const uint32_t q = boff + lane_id();
+            const uint32_t a = (li + (q >> 5)) << 2, r = q & 31u;
+            const uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
+            const uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
+            const uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
+            const uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
+            const uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
+            decode_at(lo0, mid0, hi0, r, TB0.v, TK0.v);
+            decode_at(hi0, mid1, hi1, r, TB1.v, TK1.v);
+        }
+#else
+        PZG_LANES_BEGIN(k)
+            const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
+            decode_at(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), r, PZG_LV(TB0, k), PZG_LV(TK0, k));
+            decode_at(br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r, PZG_LV(TB1, k), PZG_LV(TK1, k));
+        PZG_LANES_END
+#endif
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        prof[6] += 2;
+#endif
+        // ---- the walk: first half, and unless it ended at a stopper, the second -------------------------
+        LaneVec<uint32_t> ST;
+        uint64_t S0 = 0, S1 = 0;
+        uint32_t kend = 0;
+        do {
+#if PZG_DEVICE_PASS
+            asm("s_bitset1_b64 %0, %1" : "+s"(S0) : "s"(kend));
+#else
+            S0 |= 1ull << kend;
+#endif
+            kend += lane_get(TB0, kend);
+        } while (kend < 64u);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(ST, k) = PZG_LV(TB0, k) == 64u ? 1u : 0u;
+        PZG_LANES_END
+        const uint64_t stop0 = S0 & lanes_ballot(ST);
+        const uint32_t kend0 = stop0 ? kend - 64u : kend;  // where the first half's chain stops (a stopper) or leaves it
+        uint64_t stop1 = 0;
+        if (!stop0) {
+            kend -= 64u;
+            while (kend < 64u) {
+#if PZG_DEVICE_PASS
+                asm("s_bitset1_b64 %0, %1" : "+s"(S1) : "s"(kend));
+#else
+                S1 |= 1ull << kend;
+#endif
+                kend += lane_get(TB1, kend);
+            }
+            PZG_LANES_BEGIN(k)
+                PZG_LV(ST, k) = PZG_LV(TB1, k) == 64u ? 1u : 0u;
+            PZG_LANES_END
+            stop1 = S1 & lanes_ballot(ST);
+            kend = stop1 ? kend : kend + 64u;  // back to an offset from the cursor (a stopper at k1: k1 + 64 already)
+        } else {
+            kend = kend0;
+        }
+        bool stopper = (stop0 | stop1) != 0;
+        uint32_t consumed = kend;
+        uint64_t tokens0 = S0 & ~stop0, tokens1 = S1 & ~stop1;
+        const uint32_t room = QCAP - qn;
+        uint32_t nt0 = popc64(tokens0), nt1 = popc64(tokens1);
+        if (nt0 + nt1 > room) {  // not both halves: the first alone, the second is decoded again
+            tokens1 = 0;
+            nt1 = 0;
+            consumed = kend0;
+            stopper = stop0 != 0;
+            if (nt0 > room) {
+                LaneVec<uint32_t> FIRST_OUT;
+                PZG_LANES_BEGIN(k)
+                    PZG_LV(FIRST_OUT, k) = (((tokens0 >> k) & 1ull) && mbcnt_k(tokens0, k) == room) ? 1u : 0u;
+                PZG_LANES_END
+                consumed = ctz64(lanes_ballot(FIRST_OUT));
+                tokens0 &= (1ull << consumed) - 1ull;
+                nt0 = room;
+                stopper = false;
+            }
+        }
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        prof[7] += nt0 + nt1;
+#endif
+        LaneVec<uint32_t> DEST, R0, R1;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(DEST, k) = ((tokens0 >> k) & 1ull) ? qn + mbcnt_k(tokens0, k) : 63u;
+        PZG_LANES_END
+        lanes_scatter(R0, TK0, DEST);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(DEST, k) = ((tokens1 >> k) & 1ull) ? qn + nt0 + mbcnt_k(tokens1, k) : 63u;
+        PZG_LANES_END
+        lanes_scatter(R1, TK1, DEST);
+        PZG_LANES_BEGIN(j)
+            const uint32_t rel = j - qn;  // (wraps for j < qn)
+            PZG_LV(QT, j) = rel < nt0 ? PZG_LV(R0, j) : rel < nt0 + nt1 ? PZG_LV(R1, j) : PZG_LV(QT, j);
+        PZG_LANES_END
+        qn += nt0 + nt1;
+        br.drop_short(consumed);
         return stopper;
     }
 
@@ -965,39 +1117,34 @@ struct Decoder {
 
     PZG_FN int token_loop()
     {
+        bool stopper = false;  // the token at the cursor is one for token_step_checked()
         for (;;) {
-            // fill: decode windows until the queue is deep or the token at the cursor needs the checked path
-            bool stopper = false;
             PZG_T0(tw);
-            while (qn < QHIGH) {
-                if (!br.window_ok() || window_append()) {
-                    stopper = true;
-                    break;
-                }
-            }
+            while (!stopper && qn < QHIGH)
+                stopper = br.window2_ok() ? window_append2() : !br.window_ok() || window_append();
             PZG_ACC(4, tw);
-            PZG_T0(te);
-            if (!stopper) {
+            if (qn >= QHIGH) {
+                PZG_T0(te);
                 const int se = emit_segment();
                 PZG_ACC(12, te);
                 if (se) return se;
                 continue;
             }
-            // drain, so that whatever the checked step reports comes after everything before it
+            PZG_T0(tc);
+            int st = token_step_checked();
+            PZG_ACC(5, tc);
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+            prof[15] += 1;
+#endif
+            stopper = false;
+            if (st == ST_OK) continue;
+            // end of block or error: first everything that precedes it in the stream (an error there wins)
             while (qn != 0u) {
                 const int se = emit_segment();
                 if (se) return se;
             }
             complete_pending();
-            PZG_ACC(12, te);
-            PZG_T0(tc);
-            const int st = token_step_checked();
-            PZG_ACC(5, tc);
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-            prof[15] += 1;
-#endif
-            if (st == STEP_EOB) return ST_OK;
-            if (st != ST_OK) return st;
+            return st == STEP_EOB ? ST_OK : st;
         }
     }
 
