@@ -4,23 +4,24 @@
 //   Zlib.hs:53-69      inflateWithHeaders   -> Decoder::decode() prologue
 //   Deflate.hs:39-63   inflate/checkChecksum-> Decoder::decode() block loop + trailer
 //   Deflate.hs:65-104  inflateBlock         -> stored_block() / dynamic_header() / load_fixed_tables()
-//   Deflate.hs:106-120 runInflate           -> token_loop(): window_step() + token_step_checked()
+//   Deflate.hs:106-120 runInflate           -> token_loop(): window_append2() -> token queue -> emit_segment(); token_step_checked()
 //   Deflate.hs:124-156 getCodeLengths       -> dynamic_header()
 //   Deflate.hs:160-237 length/distance arrays -> litlen_entry()/dist_entry() (closed forms)
 //   Deflate.hs:255-292 computeCodeValues    -> build_table() (canonical codes, wave-parallel)
 //   HuffmanTree.hs     binary trie          -> two-level LDS table: a direct 2^P LUT indexed by the
 //                                             next P stream bits, then a canonical first-code/count
-//                                             table + symbol permutation for codes longer than P
+//                                             walk + ballot scan of the code lengths for codes longer than P
 //   Monad.hs:203-307   bit/byte reader      -> BitReader: coalesced dword chunks held one dword per
 //                                             lane, a per-wave bit cursor, v_readlane to fetch
 //   OutputWindow.hs    128 KiB flat window  -> 2^RING_BITS LDS ring, lane-cooperative LZ77 copy
 //   Adler32.hs         per-byte checksum    -> folded into the ring->HBM flush as a wave reduction
 //
-// The hot loop (window_step) is wave-parallel: lane k speculatively decodes the complete token
-// (literal, or length + distance with their extra bits) that would start k bits ahead of the
-// cursor -- two LDS lookups for all 64 offsets at once -- and a scalar walk then follows the real
-// chain from offset 0 with v_readlane, so no LDS round trip is paid per token.  Literal runs are
-// stored by all their lanes in one ds_write_b8; matches are lane-cooperative ring copies.
+// The hot loop is wave-parallel: lane k speculatively decodes the complete tokens (literal, or
+// length + distance with their extra bits) that would start k and k + 64 bits ahead of the cursor --
+// two LDS lookups each, for all 128 offsets at once -- and a scalar walk then follows the real chain
+// from offset 0 with v_readlane, so no LDS round trip is paid per token.  The real tokens are
+// compacted onto a per-wave token queue; emit_segment() turns the queue's head into <= 64 output
+// bytes with one ring gather and one ring store.
 //
 // The same source compiles as a host program for the CPU model tests (see wave.h).
 #pragma once
@@ -301,7 +302,7 @@ struct Decoder {
     uint32_t qn;                // tokens waiting in QT (lanes 0..qn-1), see window_append()
     LaneVec<uint32_t> QT;
 #if defined(PZG_PROFILE)
-    uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0 total, 1 header+tables, 2 token loop, 3 flush, 4 window_step, 5 checked steps, 6 windows, 7 matches
+    uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0 total, 1 header+tables, 2 token loop, 3 flush, 4 window_append, 5 checked steps, 6 windows, 7 tokens queued, 8-11 emit phases, 12 emit, 13 segments, 14 general copies, 15 checked steps
 #endif
 
     PZG_FN Decoder(WaveLds<RING_BITS> &lds) : L(lds) {}
@@ -464,7 +465,7 @@ struct Decoder {
     // than the ring its flush is long complete, so this wait is normally free.
     PZG_FN void far_fence() const
     {
-#if PZG_DEVICE_PASS
+#if PZG_DEVICE_PASS && !defined(PZG_NO_FAR_FENCE)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
