@@ -261,3 +261,19 @@ def test_incremental_protocol_and_cli(gpu_ctx, tmp_path, capsys):
     out = capsys.readouterr().out
     assert "Unexpected file name." in out and "USAGE: deflate [filename]" in out
     assert "ERROR: Ran out of data mid-decompression." in out
+
+
+def test_benchmark_harness_groups(gpu_ctx, capsys):
+    """the criterion groups of Benchmark.hs:26-46 plus the batch sweep, every sample checked against .gold."""
+    from pure_zlib_amd import benchmark
+    bs = benchmark.build_benchmarks(benchmark.DEFAULT_DIR, ["rfctest1", "zerotest2"], [1, 64], ctx=gpu_ctx)
+    names = [b[0] for b in bs]
+    assert names[:4] == ["decompression/rfctest1/normal/pzgpu", "decompression/rfctest1/normal/zlib",
+                         "decompression/rfctest1/incremental/pzgpu", "decompression/rfctest1/incremental/zlib"]
+    assert "batch/zerotest2/n=64/pzgpu" in names
+    for _name, thunk, nbytes in bs:
+        thunk()  # raises if any output differs from the gold file
+        assert nbytes > 0
+    assert benchmark.main(["--cases", "randtest1", "--time-limit", "0.05", "--batch", "8"]) == 0
+    out = capsys.readouterr().out
+    assert out.count("benchmarking ") == 5 and "full output checked" in out

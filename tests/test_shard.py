@@ -71,3 +71,21 @@ def test_two_rank_gloo_sharding(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "SHARD_OK 2 24" in out.stdout
+
+
+def test_benchmark_harness_listing_and_sampling(capsys):
+    """The harness mirror (Benchmark.hs:12-46) without a GPU: case discovery, group names, the sampler."""
+    from pure_zlib_amd import benchmark
+    cases = benchmark.find_cases(benchmark.DEFAULT_DIR)
+    assert cases == ["randtest1", "randtest2", "randtest3", "rfctest1", "rfctest2", "rfctest3",
+                     "zerotest1", "zerotest2", "zerotest3"]  # Benchmark.hs:12-24 minus tor-list (not in the reference tree)
+    assert benchmark.main(["--list", "--cases", "rfctest1", "--batch", "1,64"]) == 0
+    out = capsys.readouterr().out.split()
+    assert out == ["decompression/rfctest1/normal/pzgpu", "decompression/rfctest1/normal/zlib",
+                   "decompression/rfctest1/incremental/pzgpu", "decompression/rfctest1/incremental/zlib",
+                   "batch/rfctest1/n=1/pzgpu", "batch/rfctest1/n=64/pzgpu"]
+    z, gold = benchmark.get_files(benchmark.DEFAULT_DIR, "rfctest1")
+    assert len(benchmark.lazy_chunks(z)) == (len(z) + 32767) // 32768
+    calls = []
+    r = benchmark.measure(lambda: calls.append(1), 0.01)
+    assert r["samples"] >= 3 and len(calls) == int(r["samples"]) + 1 and r["min"] <= r["mean"]
