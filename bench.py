@@ -60,6 +60,22 @@ def build_pool(args):
             t = corpus.zipf_text(4096, seed)
             co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
             z = co.compress(t) + co.flush()
+        elif args.workload == "skewed_bytes":
+            # literal-heavy binary-like data: bytes drawn from a geometric-ish law over all 256 values, so the
+            # dynamic code has many literals longer than the primary table (exercises the second-level tables)
+            r = np.random.default_rng(seed)
+            t = np.minimum(r.geometric(0.03, size=args.blob_bytes) - 1, 255).astype(np.uint8)
+            t = ((t.astype(np.uint16) * 151 + 7) % 256).astype(np.uint8).tobytes()
+            z = zlib.compress(t, args.level)
+        elif args.workload == "html":
+            # slices of the reference's own RFC html fixtures (tests/golden/ref/rfctest*.gold)
+            if not texts and not hasattr(build_pool, "_html"):
+                d = os.path.join(ROOT, "tests", "golden", "ref")
+                build_pool._html = b"".join(open(os.path.join(d, f"rfctest{i}.gold"), "rb").read() for i in (1, 2, 3))
+            h = build_pool._html
+            o = (seed * 7919) % max(1, len(h) - args.blob_bytes)
+            t = h[o:o + args.blob_bytes]
+            z = zlib.compress(t, args.level)
         elif args.workload == "mixed":
             size = 1024 * (1 + (seed * 2654435761 >> 7) % 64)
             t = corpus.zipf_text(size, seed)
@@ -77,7 +93,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed"])
+    ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed", "skewed_bytes", "html"])
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
     ap.add_argument("--blob-bytes", type=int, default=32768)
     ap.add_argument("--level", type=int, default=6)
@@ -255,6 +271,8 @@ def main():
                               "dynamic-Huffman zlib blobs per GPU, one stream per wavefront",
                     "fixed_4k": f"BASELINE config 3: {args.streams} x 4 KiB fixed-Huffman (Z_FIXED level-1) blobs per GPU",
                     "mixed": f"BASELINE config 5 shape: {args.streams} mixed 1-64 KiB level-6 blobs per GPU",
+                    "skewed_bytes": f"diagnostic: {args.streams} x {args.blob_bytes // 1024} KiB literal-heavy skewed-byte blobs, level {args.level}",
+                    "html": f"diagnostic: {args.streams} x {args.blob_bytes // 1024} KiB slices of the reference's RFC html fixtures, level {args.level}",
                 }[args.workload],
                 "streams_per_gpu": n,
                 "distinct_blobs": npool,

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpzg.so")
+LIB_PATH = os.environ.get("PZG_LIB") or os.path.join(_HERE, "libpzg.so")  # PZG_LIB: a diagnostic build (tests/tools/exp_build.sh)
 
 RC_OK, RC_BAD_ARG, RC_NO_DEVICE, RC_HIP_ERROR, RC_NO_MEMORY = 0, -1, -2, -3, -4
 

@@ -64,7 +64,13 @@ enum : int32_t {
 
 enum { TREE_CODELEN = 0, TREE_LITLEN = 1, TREE_DIST = 2 };
 
-constexpr int LIT_BITS = 10;  // primary literal/length LUT: 2^10 x 4 B = 4 KiB
+#ifndef PZG_LIT_BITS
+#define PZG_LIT_BITS 8
+#endif
+constexpr int LIT_BITS = PZG_LIT_BITS;  // primary literal/length LUT: 2^8 x 4 B = 1 KiB (LDS is what bounds residency)
+constexpr uint32_t SUB_ENTRIES = 188;   // pool of second-level entries for literal/length codes longer than LIT_BITS
+constexpr uint32_t SUB_BITS_MAX = 5;    // a second-level table resolves at most this many further bits
+constexpr uint32_t SUB_MIN_PREFIXES = 3;  // fewer long prefixes than this: their tokens are too rare to pay for a second lookup
 constexpr int DIST_BITS = 8;  // primary distance LUT:        2^8  x 4 B = 1 KiB
 constexpr int CL_BITS = 7;    // code-length code: max length 7, the LUT is exhaustive
 constexpr uint32_t ADLER_MOD = 65521u;
@@ -81,7 +87,8 @@ enum : uint32_t {
     K_LONG = 3,          // code longer than the primary table: second level
     K_EMPTY_BRANCH = 4,  // n = depth at which the reference's walk reaches HuffmanEmpty
     K_EMPTY_TREE = 5,    // the tree has no codes at all
-    K_BADSYM = 6         // symbol 286/287 or distance symbol >= 30: value = symbol
+    K_BADSYM = 6,        // symbol 286/287 or distance symbol >= 30: value = symbol
+    K_SUB = 7            // literal/length only: second-level table at sub[value], indexed by the next n bits
 };
 
 PZG_FN uint32_t mk_entry(uint32_t n, uint32_t e, uint32_t kind, uint32_t value)
@@ -126,7 +133,6 @@ PZG_FN uint32_t codelen_entry(uint32_t sym, uint32_t n)
 struct TreeMeta {          // second-level (canonical) decode tables, index = code length 1..15
     uint16_t count[16];    // symbols of that length
     uint16_t first[16];    // first canonical code of that length
-    uint16_t offs[16];     // index of its first symbol in the sorted permutation
 };
 
 template <int RING_BITS>
@@ -134,9 +140,9 @@ struct alignas(16) WaveLds {
     uint8_t ring[1u << RING_BITS];       // OutputWindow: the last 2^RING_BITS bytes produced
     uint32_t lit_lut[1u << LIT_BITS];    // HuffmanTree (literal/length), level 1
     uint32_t dist_lut[1u << DIST_BITS];  // HuffmanTree (distance), level 1; the code-length LUT while a header is read
+    uint32_t sub[SUB_ENTRIES];           // HuffmanTree (literal/length), level 2 (see build_table)
     TreeMeta lit_meta;
     TreeMeta dist_meta;
-    TreeMeta cl_meta;
     uint32_t cnt[16];                    // histogram / running-rank scratch for build_table
     uint8_t lens[MAX_LENS + 22];         // code lengths of the block being set up
     uint8_t cl_lens[20];                 // code-length code lengths in symbol order
@@ -290,6 +296,7 @@ struct Decoder {
     uint32_t adler_a, adler_b;
     uint32_t lit_e15, dist_e15;  // Kraft totals in 2^-15 units (0 = empty tree)
     uint32_t lit_n, dist_n;      // symbols of the current block's two codes: lens[0..lit_n) and lens[lit_n..lit_n+dist_n)
+    uint32_t use_sub;            // the block's literal/length table has second-level tables: windows do the second lookup
     int32_t status;
     uint32_t detail0, detail1;
     // The last segment of a window is left pending: its bytes are gathered (LDS) and, for far sources,
@@ -326,6 +333,7 @@ struct Decoder {
         lit_e15 = uni(lit_e15);
         dist_e15 = uni(dist_e15);
         lit_n = uni(lit_n);
+        use_sub = uni(use_sub);
         dist_n = uni(dist_n);
         pend_run = uni(pend_run);
         pend_far = uni(pend_far);
@@ -577,24 +585,48 @@ struct Decoder {
         }
         wave_sync();
         // next_code (step2, Deflate.hs:273-278), offsets, Kraft sum; wave-uniform, kept in LDS (meta)
-        uint32_t code = 0, prev = 0, off = 0, e15 = 0, covered_p = 0;
+        uint32_t code = 0, prev = 0, e15 = 0, covered_p = 0, maxlen = 0;
 #pragma nounroll
         for (uint32_t l = 1; l < 16u; ++l) {
             const uint32_t c = uni(L.cnt[l]);
+            if (c) maxlen = l;
             code = (code + prev) << 1;
             prev = c;
             if (lane == 0u) {
                 meta->count[l] = (uint16_t)c;
                 meta->first[l] = (uint16_t)code;
-                meta->offs[l] = (uint16_t)off;
                 L.cnt[l] = 0u;  // becomes the running rank of pass 2
             }
-            off += c;
             e15 += c << (15u - l);
             if (l == (uint32_t)P) covered_p = code + c;  // P-bit prefixes covered by codes of length <= P: [0, covered_p)
         }
         *e15_out = e15;
         if (e15 > 32768u) return false;  // over-subscribed: some insertion must collide
+        // Second level (literal/length only).  The P-bit prefixes of the codes longer than P are the
+        // contiguous canonical range [covered_p, end_p); each of the first np_fit of them gets a table of
+        // 2^sb entries at sub[(c_p - covered_p) << sb], indexed by the next sb stream bits.  Whatever
+        // that does not resolve (longer codes, holes of an incomplete code) stays K_LONG and goes the
+        // exact way: token_step_checked() -> decode_long().
+        uint32_t sb = 0, np_fit = 0;
+        if (TREE == TREE_LITLEN) {
+            uint32_t end_p = (e15 + (1u << (15u - P)) - 1u) >> (15u - P);
+            if (end_p > (1u << P)) end_p = 1u << P;
+            const uint32_t np = end_p > covered_p ? end_p - covered_p : 0u;
+            if (maxlen > (uint32_t)P && np >= SUB_MIN_PREFIXES) {
+                sb = maxlen - (uint32_t)P < SUB_BITS_MAX ? maxlen - (uint32_t)P : SUB_BITS_MAX;
+                while (sb > 1u && (np << sb) > SUB_ENTRIES) --sb;
+                np_fit = (SUB_ENTRIES >> sb) < np ? (SUB_ENTRIES >> sb) : np;
+            }
+            use_sub = np_fit != 0u ? 1u : 0u;
+#if defined(PZG_NO_SUB)
+            use_sub = 0u;  // (experiment: the one-level window code only)
+#endif
+#pragma nounroll
+            for (uint32_t i0 = 0; i0 < (np_fit << sb); i0 += PZG_WAVE) {
+                const uint32_t i = i0 + lane;
+                if (i < (np_fit << sb)) L.sub[i] = mk_entry(0, 0, K_LONG, 0);
+            }
+        }
         wave_sync();
         // default fill: patterns no code of length <= P covers are either the prefix of a longer
         // code (K_LONG) or lead the reference's trie walk into HuffmanEmpty at some depth d
@@ -608,7 +640,8 @@ struct Decoder {
                 if (e15 == 0u) {
                     ent = mk_entry(1, 0, K_EMPTY_TREE, 0);
                 } else if ((c_p << (15u - P)) < e15) {
-                    ent = mk_entry(0, 0, K_LONG, 0);
+                    ent = (TREE == TREE_LITLEN && c_p - covered_p < np_fit) ? mk_entry(sb, 0, K_SUB, (c_p - covered_p) << sb)
+                                                                           : mk_entry(0, 0, K_LONG, 0);
                 } else {
                     uint32_t d = (uint32_t)P;  // smallest d whose d-bit prefix is at or past the end of all codes
 #pragma unroll
@@ -648,6 +681,15 @@ struct Decoder {
                     const uint32_t rev = bitrev32(c) >> (32u - len);
 #pragma nounroll
                     for (uint32_t idx = rev; idx < (1u << P); idx += (1u << len)) lut[idx] = ent;
+                } else if (TREE == TREE_LITLEN && np_fit != 0u) {
+                    const uint32_t rl = len - (uint32_t)P;   // bits of the code past its P-bit prefix
+                    const uint32_t pfx = (c >> rl) - covered_p;
+                    if (rl <= sb && pfx < np_fit) {
+                        const uint32_t ent = litlen_entry(s, len);
+                        const uint32_t rev = bitrev32(c & ((1u << rl) - 1u)) >> (32u - rl);  // those bits in stream order
+#pragma nounroll
+                        for (uint32_t idx = rev; idx < (1u << sb); idx += (1u << rl)) L.sub[(pfx << sb) + idx] = ent;
+                    }
                 }
             }
         }
@@ -741,7 +783,7 @@ struct Decoder {
         uint32_t bits = br.peek32();
         uint32_t e = uni(L.lit_lut[bits & ((1u << LIT_BITS) - 1u)]);
         uint32_t kind = ent_kind(e);
-        if (kind == K_LONG) {
+        if (kind == K_LONG || kind == K_SUB) {  // the exact walk, whether or not a second-level table exists
             e = decode_long<TREE_LITLEN>(bits, &L.lit_meta, L.lens, lit_n, lit_e15);
             kind = ent_kind(e);
         }
@@ -800,21 +842,70 @@ struct Decoder {
 
     // One lane's speculative decode: the token whose first bit is bit r of (hi:mid:lo).
     // tb = its length in bits, 64 if it is not a plain literal/match (the walk stops there); tk = the token.
-    PZG_FN void decode_at(uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r, uint32_t &tb, uint32_t &tk)
+    // The three stages of one lane's speculative decode, split so that a 128-bit window can run its two
+    // decodes in lockstep (both LDS lookups of a stage are in flight together).
+    // When the block's literal/length table has second-level tables (use_sub), long codes are looked up there.
+    struct Spec {
+        uint32_t w_lo, w_hi, e, w2, d;
+    };
+    PZG_FN void spec_bits(Spec &t, uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r)
     {
-        const uint32_t w_lo = funnel(mid, lo, r), w_hi = funnel(hi, mid, r);   // 64 stream bits from the token's first
-        const uint32_t e = L.lit_lut[w_lo & ((1u << LIT_BITS) - 1u)];
+        t.w_lo = funnel(mid, lo, r);  // 64 stream bits from the token's first
+        t.w_hi = funnel(hi, mid, r);
+        t.e = L.lit_lut[t.w_lo & ((1u << LIT_BITS) - 1u)];
+    }
+    PZG_FN void spec_sub(Spec &t)
+    {
+        const bool is_sub = ent_kind(t.e) == K_SUB;
+        const uint32_t i2 = is_sub ? ent_val(t.e) + ((t.w_lo >> LIT_BITS) & ((1u << ent_n(t.e)) - 1u)) : 0u;
+        const uint32_t e2 = L.sub[i2];
+        t.e = is_sub ? e2 : t.e;
+    }
+    PZG_FN void spec_dist(Spec &t)
+    {
+        t.w2 = funnel(t.w_hi, t.w_lo, ent_n(t.e) + ent_e(t.e));  // bits after the length code (<= 20 in)
+        t.d = L.dist_lut[t.w2 & ((1u << DIST_BITS) - 1u)];
+    }
+    // tb = the token's length in bits, 64 if it is not a plain literal/match (the walk stops there); tk = the token
+    PZG_FN void spec_finish(const Spec &t, uint32_t &tb, uint32_t &tk)
+    {
+        const uint32_t e = t.e, d = t.d;
         const uint32_t n = ent_n(e), ex = ent_e(e), kind = ent_kind(e);
-        const uint32_t o = n + ex;                                             // <= 20
-        const uint32_t lenv = ent_val(e) + ((w_lo >> n) & ((1u << ex) - 1u));  // literal byte when kind == K_LIT
-        const uint32_t w2 = funnel(w_hi, w_lo, o);                             // bits after the length code
-        const uint32_t d = L.dist_lut[w2 & ((1u << DIST_BITS) - 1u)];
-        const uint32_t dn = ent_n(d), dex = ent_e(d);                          // dn + dex <= 28
-        const uint32_t dist = ent_val(d) + ((w2 >> dn) & ((1u << dex) - 1u));
+        const uint32_t lenv = ent_val(e) + ((t.w_lo >> n) & ((1u << ex) - 1u));  // literal byte when kind == K_LIT
+        const uint32_t dn = ent_n(d), dex = ent_e(d);                            // n + ex <= 20, dn + dex <= 28
+        const uint32_t dist = ent_val(d) + ((t.w2 >> dn) & ((1u << dex) - 1u));
         const bool is_lit = kind == K_LIT;
         const bool is_match = kind == K_BASE && ent_kind(d) == K_BASE;
-        tb = is_lit ? n : is_match ? o + dn + dex : 64u;
-        tk = is_lit ? (LIT_FLAG | (1u << 16) | (lenv & 0xffu)) : is_match ? ((lenv << 16) | dist) : 0u;
+        uint32_t tk_match = (lenv << 16) | dist;
+#if PZG_DEVICE_PASS
+        asm("" : "+v"(tk_match));  // keep the match arithmetic out of a lane-dependent branch (straight-line code)
+#endif
+        tb = is_lit ? n : is_match ? n + ex + dn + dex : 64u;
+        tk = is_lit ? (LIT_FLAG | (1u << 16) | (lenv & 0xffu)) : is_match ? tk_match : 0u;
+    }
+    PZG_FN void decode_at(uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r, uint32_t &tb, uint32_t &tk)
+    {
+        Spec t;
+        spec_bits(t, lo, mid, hi, r);
+        if (use_sub) spec_sub(t);  // wave-uniform
+        spec_dist(t);
+        spec_finish(t, tb, tk);
+    }
+    // two independent decodes, stage by stage
+    PZG_FN void decode_pair(uint32_t lo0, uint32_t mid0, uint32_t hi0, uint32_t mid1, uint32_t hi1, uint32_t r, uint32_t &tb0,
+                            uint32_t &tk0, uint32_t &tb1, uint32_t &tk1)
+    {
+        Spec a, b;
+        spec_bits(a, lo0, mid0, hi0, r);
+        spec_bits(b, hi0, mid1, hi1, r);
+        if (use_sub) {  // wave-uniform
+            spec_sub(a);
+            spec_sub(b);
+        }
+        spec_dist(a);
+        spec_dist(b);
+        spec_finish(a, tb0, tk0);
+        spec_finish(b, tb1, tk1);
     }
 
     // Precondition: at least WINDOW_MIN_BITS real bits follow the cursor, so every token that
@@ -923,14 +1014,13 @@ struct Decoder {
             const uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
             const uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
             const uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
-            decode_at(lo0, mid0, hi0, r, TB0.v, TK0.v);
-            decode_at(hi0, mid1, hi1, r, TB1.v, TK1.v);
+            decode_pair(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
         }
 #else
         PZG_LANES_BEGIN(k)
             const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
-            decode_at(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), r, PZG_LV(TB0, k), PZG_LV(TK0, k));
-            decode_at(br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r, PZG_LV(TB1, k), PZG_LV(TK1, k));
+            decode_pair(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
+                             PZG_LV(TB0, k), PZG_LV(TK0, k), PZG_LV(TB1, k), PZG_LV(TK1, k));
         PZG_LANES_END
 #endif
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
@@ -1239,7 +1329,7 @@ struct Decoder {
         if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = 0u;  // the tables are about to be overwritten
         lit_n = hlit;
         uint32_t cl_e15;
-        if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, &L.cl_meta, &cl_e15))
+        if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, &L.lit_meta, &cl_e15)  /* (its meta is never read; lit_meta is rebuilt below) */)
             return fail(ST_HUFF_BUILD, TREE_CODELEN, block_bit);
         // getCodeLengths (Deflate.hs:124-156) over HLIT+HDIST as ONE sequence
         const uint32_t maxl = hlit + hdist;
@@ -1300,6 +1390,7 @@ struct Decoder {
         adler_b = 0;
         lit_e15 = dist_e15 = 0;
         lit_n = dist_n = 0;
+        use_sub = 0;
         pend_run = pend_far = 0;
         qn = 0;
         status = ST_OK;

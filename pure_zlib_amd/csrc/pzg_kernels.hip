@@ -17,8 +17,22 @@ namespace pzg {
 // ------------------------------------------------------------------------------------------------
 // inflate: grid = number of streams, block = 64 threads.  LDS per workgroup = sizeof(WaveLds) =
 // 38.7 KiB at RING_BITS = 15, so four stream-waves are resident per CU (one per SIMD).
+// Waves per SIMD each instance is compiled for (its VGPR budget: 512 / waves, in steps of 8) and the
+// resident stream-waves per CU that follow from it and from sizeof(WaveLds) against the 160 KiB of LDS.
+#ifndef PZG_MIN_WAVES_11
+#define PZG_MIN_WAVES_11 7
+#endif
+constexpr int waves_per_simd(int ring_bits) { return ring_bits <= 11 ? PZG_MIN_WAVES_11 : ring_bits == 12 ? 5 : 4; }
+template <int RING_BITS>
+constexpr uint32_t waves_per_cu()
+{
+    constexpr uint32_t by_lds = (160u * 1024u) / (uint32_t)((sizeof(WaveLds<RING_BITS>) + 511u) / 512u * 512u);
+    constexpr uint32_t by_vgpr = 4u * (uint32_t)waves_per_simd(RING_BITS);
+    return by_lds < by_vgpr ? by_lds : by_vgpr;
+}
+
 template <int RING_BITS, bool FIXUP>
-__global__ __launch_bounds__(64, (RING_BITS <= 11 ? 5 : 4)) void inflate_kernel(InflateArgs a)
+__global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(InflateArgs a)
 {
     __shared__ WaveLds<RING_BITS> lds;
     if (FIXUP && __builtin_nontemporal_load(a.counter + 1) == 0u) return;  // nothing was handed back
@@ -66,9 +80,9 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     if (a.n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back
     if (e != hipSuccess) return e;
-    // Resident stream-waves per CU: LDS-bound (160 KiB / sizeof(WaveLds)) for the big rings, VGPR-bound
-    // (<= 128 VGPRs: 4 waves per SIMD; <= 96 for ring 11: 5 per SIMD) for the small ones.
-    const uint32_t per_cu = ring_bits == 15 ? 4u : ring_bits == 14 ? 7u : ring_bits == 13 ? 11u : ring_bits == 12 ? 16u : 20u;
+    // Resident stream-waves per CU: 4 / 8 / 13 / 20 / 28 for rings 15 .. 11 (LDS-bound except ring 11: 72 VGPRs, 7 per SIMD)
+    const uint32_t per_cu = ring_bits == 15 ? waves_per_cu<15>() : ring_bits == 14 ? waves_per_cu<14>()
+                            : ring_bits == 13 ? waves_per_cu<13>() : ring_bits == 12 ? waves_per_cu<12>() : waves_per_cu<11>();
     uint32_t waves = (uint32_t)num_cus * per_cu;
     if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);  // experiment knob
     if (waves > a.n) waves = a.n;
