@@ -60,21 +60,11 @@ def build_pool(args):
             t = corpus.zipf_text(4096, seed)
             co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
             z = co.compress(t) + co.flush()
-        elif args.workload == "skewed_bytes":
-            # literal-heavy binary-like data: bytes drawn from a geometric-ish law over all 256 values, so the
-            # dynamic code has many literals longer than the primary table (exercises the second-level tables)
-            r = np.random.default_rng(seed)
-            t = np.minimum(r.geometric(0.03, size=args.blob_bytes) - 1, 255).astype(np.uint8)
-            t = ((t.astype(np.uint16) * 151 + 7) % 256).astype(np.uint8).tobytes()
+        elif args.workload == "skewed_bytes":  # literal-heavy, many codes longer than the primary table
+            t = corpus.skewed_bytes(args.blob_bytes, seed)
             z = zlib.compress(t, args.level)
-        elif args.workload == "html":
-            # slices of the reference's own RFC html fixtures (tests/golden/ref/rfctest*.gold)
-            if not texts and not hasattr(build_pool, "_html"):
-                d = os.path.join(ROOT, "tests", "golden", "ref")
-                build_pool._html = b"".join(open(os.path.join(d, f"rfctest{i}.gold"), "rb").read() for i in (1, 2, 3))
-            h = build_pool._html
-            o = (seed * 7919) % max(1, len(h) - args.blob_bytes)
-            t = h[o:o + args.blob_bytes]
+        elif args.workload == "html":  # slices of the reference's own RFC html fixtures
+            t = corpus.html_slice(args.blob_bytes, seed)
             z = zlib.compress(t, args.level)
         elif args.workload == "mixed":
             size = 1024 * (1 + (seed * 2654435761 >> 7) % 64)

@@ -100,6 +100,29 @@ def corrupt(z: bytes, seed: int) -> bytes:
     return bytes(b)
 
 
+def skewed_bytes(nbytes: int, seed: int) -> bytes:
+    """Literal-heavy binary-like data: all 256 byte values under a geometric law, so a dynamic code has
+    many literals longer than the primary table (the kernel's second-level tables) and few matches."""
+    r = np.random.default_rng(seed)
+    t = np.minimum(r.geometric(0.03, size=nbytes) - 1, 255).astype(np.uint16)
+    return ((t * 151 + 7) % 256).astype(np.uint8).tobytes()
+
+
+_HTML = None
+
+
+def html_slice(nbytes: int, seed: int) -> bytes:
+    """A slice of the reference's own RFC html fixtures (tests/golden/ref/rfctest*.gold): ~95 distinct
+    symbols, literal/length codes up to 13 bits."""
+    global _HTML
+    if _HTML is None:
+        import os
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref")
+        _HTML = b"".join(open(os.path.join(d, f"rfctest{i}.gold"), "rb").read() for i in (1, 2, 3))
+    o = (seed * 7919) % max(1, len(_HTML) - nbytes)
+    return _HTML[o:o + nbytes]
+
+
 def fixed_blob(nbytes: int, seed: int) -> bytes:
     """BASELINE config 3: level-1 with Z_FIXED so the block really is BTYPE=1."""
     co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)

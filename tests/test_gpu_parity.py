@@ -277,3 +277,32 @@ def test_benchmark_harness_groups(gpu_ctx, capsys):
     assert benchmark.main(["--cases", "randtest1", "--time-limit", "0.05", "--batch", "8"]) == 0
     out = capsys.readouterr().out
     assert out.count("benchmarking ") == 5 and "full output checked" in out
+
+
+def test_long_codes_second_level_tables(ctx, oracle):
+    """Literal-heavy and html corpora: literal/length codes longer than the 8-bit primary table (second-level
+    tables in the windows, the exact walk in the checked path), valid and corrupted, against zlib and the oracle."""
+    streams, datas = [], []
+    for seed in range(600):
+        n = [700, 3000, 20000, 33000, 70000][seed % 5]
+        d = corpus.skewed_bytes(n, seed) if seed % 2 else corpus.html_slice(n, seed)
+        streams.append(corpus.compress_variant(d, seed) if seed % 3 == 0 else zlib.compress(d, 1 + seed % 9))
+        datas.append(d)
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, [len(d) for d in datas])
+    for k in range(len(streams)):
+        assert status[k] == 0 and outs[k] == datas[k], (k, status[k], detail[k])
+        assert int(adler[k]) == zlib.adler32(datas[k]) and int(in_used[k]) == len(streams[k])
+    bad = [corpus.corrupt(streams[k % 600], 9000 + k) for k in range(1500)]
+    caps = [len(datas[k % 600]) + 64 for k in range(1500)]
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, bad, caps)
+    import pure_zlib_amd.zlib as Z
+    for k in range(len(bad)):
+        r, o = oracle.decompress(bad[k], caps[k])
+        assert int(status[k]) == r.status, (k, status[k], r.status, r.message)
+        if r.status == 0:
+            assert outs[k] == o and int(adler[k]) == r.adler and int(in_used[k]) == r.in_used
+        elif r.status == 14:
+            assert int(out_len[k]) == r.out_len
+        else:
+            err = Z.error_from_status(bad[k], int(status[k]), detail[k])
+            assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())

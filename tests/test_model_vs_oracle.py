@@ -105,3 +105,20 @@ def test_model_far_window_and_small_capacity(model, oracle, rb):
             ro, oo = oracle.decompress(z, cap)
             rm, om = model(z, cap, rb)
             assert (ro.status, ro.out_len) == (rm.status, rm.out_len) and oo == om, (seed, cap)
+
+
+@pytest.mark.parametrize("rb", [15, 11])
+def test_model_long_codes_second_level_tables(model, oracle, rb):
+    """Codes longer than the 8-bit primary table: second-level tables in the windows, the exact walk in
+    the checked path; every level and strategy, plus corrupted variants against the oracle."""
+    for seed in range(36):
+        n = [3000, 20000, 40000][seed % 3]
+        d = corpus.skewed_bytes(n, seed) if seed % 2 else corpus.html_slice(n, seed)
+        z = corpus.compress_variant(d, seed) if seed % 3 == 0 else zlib.compress(d, 1 + seed % 9)
+        r, out = model(z, len(d), rb)
+        assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), seed
+        for c in range(6):
+            zc = corpus.corrupt(z, seed * 16 + c)
+            ro, oo = oracle.decompress(zc, len(d) + 64)
+            rm, om = model(zc, len(d) + 64, rb)
+            assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
