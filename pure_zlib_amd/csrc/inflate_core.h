@@ -88,7 +88,7 @@ enum : uint32_t {
     K_EMPTY_BRANCH = 4,  // n = depth at which the reference's walk reaches HuffmanEmpty
     K_EMPTY_TREE = 5,    // the tree has no codes at all
     K_BADSYM = 6,        // symbol 286/287 or distance symbol >= 30: value = symbol
-    K_SUB = 7            // literal/length only: second-level table at sub[value], indexed by the next n bits
+    K_SUB = 7            // second-level table at sub[value], indexed by the next n bits
 };
 
 PZG_FN uint32_t mk_entry(uint32_t n, uint32_t e, uint32_t kind, uint32_t value)
@@ -296,7 +296,8 @@ struct Decoder {
     uint32_t adler_a, adler_b;
     uint32_t lit_e15, dist_e15;  // Kraft totals in 2^-15 units (0 = empty tree)
     uint32_t lit_n, dist_n;      // symbols of the current block's two codes: lens[0..lit_n) and lens[lit_n..lit_n+dist_n)
-    uint32_t use_sub;            // the block's literal/length table has second-level tables: windows do the second lookup
+    uint32_t use_sub;            // the block's literal/length code has enough long prefixes: windows do the second lookup
+    uint32_t lit_sub_used;       // second-level entries taken by the literal/length code (the distance code's follow)
     int32_t status;
     uint32_t detail0, detail1;
     // The last segment of a window is left pending: its bytes are gathered (LDS) and, for far sources,
@@ -334,6 +335,7 @@ struct Decoder {
         dist_e15 = uni(dist_e15);
         lit_n = uni(lit_n);
         use_sub = uni(use_sub);
+        lit_sub_used = uni(lit_sub_used);
         dist_n = uni(dist_n);
         pend_run = uni(pend_run);
         pend_far = uni(pend_far);
@@ -602,29 +604,37 @@ struct Decoder {
         }
         *e15_out = e15;
         if (e15 > 32768u) return false;  // over-subscribed: some insertion must collide
-        // Second level (literal/length only).  The P-bit prefixes of the codes longer than P are the
-        // contiguous canonical range [covered_p, end_p); each of the first np_fit of them gets a table of
-        // 2^sb entries at sub[(c_p - covered_p) << sb], indexed by the next sb stream bits.  Whatever
-        // that does not resolve (longer codes, holes of an incomplete code) stays K_LONG and goes the
-        // exact way: token_step_checked() -> decode_long().
-        uint32_t sb = 0, np_fit = 0;
-        if (TREE == TREE_LITLEN) {
+        // Second level (literal/length and distance).  The P-bit prefixes of the codes longer than P are
+        // the contiguous canonical range [covered_p, end_p); each of the first np_fit of them gets a table
+        // of 2^sb entries at sub[sub0 + ((c_p - covered_p) << sb)], indexed by the next sb stream bits.
+        // The literal/length tables come first in the pool, the distance tables take what is left.
+        // token_step_checked() always resolves through them; the windows do their second lookup only
+        // when the literal/length code has enough long prefixes for it to pay (use_sub).  Whatever the
+        // tables do not resolve (longer codes, holes of an incomplete code) stays K_LONG and goes the
+        // exact way: decode_long().
+        uint32_t sb = 0, np_fit = 0, sub0 = 0;
+        if (TREE != TREE_CODELEN) {
+            sub0 = TREE == TREE_DIST ? lit_sub_used : 0u;
+            const uint32_t pool = SUB_ENTRIES - sub0;
             uint32_t end_p = (e15 + (1u << (15u - P)) - 1u) >> (15u - P);
             if (end_p > (1u << P)) end_p = 1u << P;
             const uint32_t np = end_p > covered_p ? end_p - covered_p : 0u;
-            if (maxlen > (uint32_t)P && np >= SUB_MIN_PREFIXES) {
+            if (maxlen > (uint32_t)P && np != 0u && pool >= 2u) {
                 sb = maxlen - (uint32_t)P < SUB_BITS_MAX ? maxlen - (uint32_t)P : SUB_BITS_MAX;
-                while (sb > 1u && (np << sb) > SUB_ENTRIES) --sb;
-                np_fit = (SUB_ENTRIES >> sb) < np ? (SUB_ENTRIES >> sb) : np;
+                while (sb > 1u && (np << sb) > pool) --sb;
+                np_fit = (pool >> sb) < np ? (pool >> sb) : np;
             }
-            use_sub = np_fit != 0u ? 1u : 0u;
+            if (TREE == TREE_LITLEN) {
+                lit_sub_used = np_fit << sb;
+                use_sub = np_fit >= SUB_MIN_PREFIXES ? 1u : 0u;
 #if defined(PZG_NO_SUB)
-            use_sub = 0u;  // (experiment: the one-level window code only)
+                use_sub = 0u;  // (experiment: the one-level window code only)
 #endif
+            }
 #pragma nounroll
             for (uint32_t i0 = 0; i0 < (np_fit << sb); i0 += PZG_WAVE) {
                 const uint32_t i = i0 + lane;
-                if (i < (np_fit << sb)) L.sub[i] = mk_entry(0, 0, K_LONG, 0);
+                if (i < (np_fit << sb)) L.sub[sub0 + i] = mk_entry(0, 0, K_LONG, 0);
             }
         }
         wave_sync();
@@ -640,7 +650,7 @@ struct Decoder {
                 if (e15 == 0u) {
                     ent = mk_entry(1, 0, K_EMPTY_TREE, 0);
                 } else if ((c_p << (15u - P)) < e15) {
-                    ent = (TREE == TREE_LITLEN && c_p - covered_p < np_fit) ? mk_entry(sb, 0, K_SUB, (c_p - covered_p) << sb)
+                    ent = (TREE != TREE_CODELEN && c_p - covered_p < np_fit) ? mk_entry(sb, 0, K_SUB, sub0 + ((c_p - covered_p) << sb))
                                                                            : mk_entry(0, 0, K_LONG, 0);
                 } else {
                     uint32_t d = (uint32_t)P;  // smallest d whose d-bit prefix is at or past the end of all codes
@@ -681,14 +691,14 @@ struct Decoder {
                     const uint32_t rev = bitrev32(c) >> (32u - len);
 #pragma nounroll
                     for (uint32_t idx = rev; idx < (1u << P); idx += (1u << len)) lut[idx] = ent;
-                } else if (TREE == TREE_LITLEN && np_fit != 0u) {
+                } else if (TREE != TREE_CODELEN && np_fit != 0u) {
                     const uint32_t rl = len - (uint32_t)P;   // bits of the code past its P-bit prefix
                     const uint32_t pfx = (c >> rl) - covered_p;
                     if (rl <= sb && pfx < np_fit) {
-                        const uint32_t ent = litlen_entry(s, len);
+                        const uint32_t ent = TREE == TREE_LITLEN ? litlen_entry(s, len) : dist_entry(s, len);
                         const uint32_t rev = bitrev32(c & ((1u << rl) - 1u)) >> (32u - rl);  // those bits in stream order
 #pragma nounroll
-                        for (uint32_t idx = rev; idx < (1u << sb); idx += (1u << rl)) L.sub[(pfx << sb) + idx] = ent;
+                        for (uint32_t idx = rev; idx < (1u << sb); idx += (1u << rl)) L.sub[sub0 + (pfx << sb) + idx] = ent;
                     }
                 }
             }
@@ -783,7 +793,11 @@ struct Decoder {
         uint32_t bits = br.peek32();
         uint32_t e = uni(L.lit_lut[bits & ((1u << LIT_BITS) - 1u)]);
         uint32_t kind = ent_kind(e);
-        if (kind == K_LONG || kind == K_SUB) {  // the exact walk, whether or not a second-level table exists
+        if (kind == K_SUB) {  // second level: one more (wave-uniform) lookup
+            e = uni(L.sub[ent_val(e) + ((bits >> LIT_BITS) & ((1u << ent_n(e)) - 1u))]);
+            kind = ent_kind(e);
+        }
+        if (kind == K_LONG) {  // the exact walk for whatever the tables do not hold
             e = decode_long<TREE_LITLEN>(bits, &L.lit_meta, L.lens, lit_n, lit_e15);
             kind = ent_kind(e);
         }
@@ -802,6 +816,10 @@ struct Decoder {
             bits = br.peek32();
             uint32_t d = uni(L.dist_lut[bits & ((1u << DIST_BITS) - 1u)]);
             uint32_t dk = ent_kind(d);
+            if (dk == K_SUB) {
+                d = uni(L.sub[ent_val(d) + ((bits >> DIST_BITS) & ((1u << ent_n(d)) - 1u))]);
+                dk = ent_kind(d);
+            }
             if (dk == K_LONG) {
                 d = decode_long<TREE_DIST>(bits, &L.dist_meta, L.lens + lit_n, dist_n, dist_e15);
                 dk = ent_kind(d);
@@ -1391,6 +1409,7 @@ struct Decoder {
         lit_e15 = dist_e15 = 0;
         lit_n = dist_n = 0;
         use_sub = 0;
+        lit_sub_used = 0;
         pend_run = pend_far = 0;
         qn = 0;
         status = ST_OK;
