@@ -70,7 +70,10 @@ enum { TREE_CODELEN = 0, TREE_LITLEN = 1, TREE_DIST = 2 };
 constexpr int LIT_BITS = PZG_LIT_BITS;  // primary literal/length LUT: 2^8 x 4 B = 1 KiB (LDS is what bounds residency)
 constexpr uint32_t SUB_ENTRIES = 188;   // pool of second-level entries for literal/length codes longer than LIT_BITS
 constexpr uint32_t SUB_BITS_MAX = 5;    // a second-level table resolves at most this many further bits
-constexpr uint32_t SUB_MIN_PREFIXES = 3;  // fewer long prefixes than this: their tokens are too rare to pay for a second lookup
+#ifndef PZG_SUB_MIN
+#define PZG_SUB_MIN 3
+#endif
+constexpr uint32_t SUB_MIN_PREFIXES = PZG_SUB_MIN;  // fewer long prefixes than this: their tokens are too rare to pay for a second lookup in the windows
 constexpr int DIST_BITS = 8;  // primary distance LUT:        2^8  x 4 B = 1 KiB
 constexpr int CL_BITS = 7;    // code-length code: max length 7, the LUT is exhaustive
 constexpr uint32_t ADLER_MOD = 65521u;

@@ -15,19 +15,23 @@
 namespace pzg {
 
 // ------------------------------------------------------------------------------------------------
-// inflate: grid = number of streams, block = 64 threads.  LDS per workgroup = sizeof(WaveLds) =
-// 38.7 KiB at RING_BITS = 15, so four stream-waves are resident per CU (one per SIMD).
+// inflate: a persistent grid of one-wave workgroups (block = 64 threads), each pulling stream indices
+// from a device counter.  LDS per workgroup = sizeof(WaveLds): 35.5 KiB at RING_BITS = 15 (four
+// stream-waves per CU, one per SIMD) down to 5.5 KiB at RING_BITS = 11 (28 per CU).
 // Waves per SIMD each instance is compiled for (its VGPR budget: 512 / waves, in steps of 8) and the
 // resident stream-waves per CU that follow from it and from sizeof(WaveLds) against the 160 KiB of LDS.
 #ifndef PZG_MIN_WAVES_11
 #define PZG_MIN_WAVES_11 7
 #endif
-constexpr int waves_per_simd(int ring_bits) { return ring_bits <= 11 ? PZG_MIN_WAVES_11 : ring_bits == 12 ? 5 : 4; }
+constexpr int waves_per_simd(int ring_bits)
+{
+    return ring_bits <= 11 ? PZG_MIN_WAVES_11 : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
+}
 template <int RING_BITS>
 constexpr uint32_t waves_per_cu()
 {
     constexpr uint32_t by_lds = (160u * 1024u) / (uint32_t)((sizeof(WaveLds<RING_BITS>) + 511u) / 512u * 512u);
-    constexpr uint32_t by_vgpr = 4u * (uint32_t)waves_per_simd(RING_BITS);
+    constexpr uint32_t by_vgpr = 4u * (uint32_t)(RING_BITS >= 13 ? 4 : waves_per_simd(RING_BITS));  // rings 13-15 fit 128 VGPRs
     return by_lds < by_vgpr ? by_lds : by_vgpr;
 }
 

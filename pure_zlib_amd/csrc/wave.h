@@ -158,7 +158,7 @@ template <class T>
 struct LaneVec {
     T v;
 };
-#define PZG_LANES_BEGIN(k) { const uint32_t k = ::pzg::lane_id();
+#define PZG_LANES_BEGIN(k) { [[maybe_unused]] const uint32_t k = ::pzg::lane_id();
 #define PZG_LANES_END }
 #define PZG_LV(x, k) ((x).v)
 #else
