@@ -1,0 +1,317 @@
+// codec_compression_zlib.hpp -- the reference's module surface in C++, over the C ABI of include/pzg.h.
+//
+// pure-zlib is compiled (Haskell) code whose boundary is a module signature, not an FFI
+// (src/Codec/Compression/Zlib.hs:3-8).  No GHC exists in this project's image, so next to the Haskell
+// shim of INTEGRATION.md (source only) this header is the host side that is actually compiled and run:
+// same names, same argument meaning, same error behaviour, header-only, C++17, no dependency beyond
+// libpzg.so.  There is no CPU decode path here either: construction fails without a GPU.
+//
+//   Codec.Compression.Zlib                      namespace Codec::Compression::Zlib
+//   ----------------------------------------    -----------------------------------------------
+//   data DecompressionError (Monad.hs:87-104)   struct DecompressionError { constructor, message; show(); == }
+//   L.ByteString (lazy = list of chunks)        using LazyByteString = std::vector<std::string>
+//   decompress      (Zlib.hs:32-51)             Either decompress(const LazyByteString&)
+//   decompressMany  (new)            std::vector<Either> decompressMany(const std::vector<LazyByteString>&)
+//   ZlibDecoder / decompressIncremental         class ZlibDecoder { NeedMore / Chunk / Done / DecompError }
+//     (Monad.hs:163-167, Zlib.hs:29-30)
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pzg.h"
+
+namespace Codec {
+namespace Compression {
+namespace Zlib {
+
+using ByteString = std::string;                   // strict bytes
+using LazyByteString = std::vector<ByteString>;   // lazy bytes: the chunk list (never holds empty chunks)
+
+inline LazyByteString fromStrict(const ByteString &b) { return b.empty() ? LazyByteString{} : LazyByteString{b}; }
+inline ByteString toStrict(const LazyByteString &l)
+{
+    ByteString s;
+    for (const auto &c : l) s += c;
+    return s;
+}
+// L.readFile hands out defaultChunkSize (32 KiB - overhead; 32 KiB here) pieces
+inline LazyByteString fromChunksOf(const ByteString &b, size_t chunk = 32768)
+{
+    LazyByteString l;
+    for (size_t i = 0; i < b.size(); i += chunk) l.push_back(b.substr(i, chunk));
+    return l;
+}
+
+// ---- Monad.hs:87-104 ---------------------------------------------------------------------------
+struct DecompressionError {
+    enum Constructor {
+        HuffmanTreeError,
+        FormatError,
+        DecompressionError_,  // the constructor that shares the type's name
+        HeaderError,
+        ChecksumError,
+        ReferenceThrows  // inputs on which the reference throws a Haskell exception; a value here
+    };
+    Constructor constructor = DecompressionError_;
+    std::string message;
+    int32_t status = -1;  // the ABI's per-stream status this was rebuilt from
+    uint32_t detail[2] = {0, 0};
+
+    // instance Show (Monad.hs:95-102)
+    std::string show() const
+    {
+        static const char *prefix[] = {"Huffman tree manipulation error: ", "Block format error: ", "Decompression error: ",
+                                       "Header error: ", "Checksum error: ", ""};
+        return std::string(prefix[constructor]) + message;
+    }
+    // deriving Eq
+    bool operator==(const DecompressionError &o) const { return constructor == o.constructor && message == o.message; }
+    bool operator!=(const DecompressionError &o) const { return !(*this == o); }
+};
+
+// Either DecompressionError L.ByteString
+struct Either {
+    bool is_right = false;
+    DecompressionError left;
+    ByteString right;  // (strict: the concatenated output; lazy-ByteString equality ignores chunking)
+    static Either Left(DecompressionError e)
+    {
+        Either r;
+        r.left = std::move(e);
+        return r;
+    }
+    static Either Right(ByteString b)
+    {
+        Either r;
+        r.is_right = true;
+        r.right = std::move(b);
+        return r;
+    }
+};
+
+namespace detail {
+
+inline DecompressionError::Constructor constructor_of(int32_t status)
+{
+    switch (status) {
+    case PZG_E_TRUNCATED:
+    case PZG_E_DATA_REMAINING: return DecompressionError::DecompressionError_;
+    case PZG_E_HDR_FCHECK:
+    case PZG_E_HDR_METHOD:
+    case PZG_E_HDR_WINDOW: return DecompressionError::HeaderError;
+    case PZG_E_FMT_LEN_NLEN:
+    case PZG_E_FMT_BTYPE: return DecompressionError::FormatError;
+    case PZG_E_HUFF_BUILD:
+    case PZG_E_HUFF_EMPTY_TREE:
+    case PZG_E_HUFF_EMPTY_BRANCH: return DecompressionError::HuffmanTreeError;
+    case PZG_E_CHECKSUM: return DecompressionError::ChecksumError;
+    default: return DecompressionError::ReferenceThrows;
+    }
+}
+
+// rebuild the reference's error value (constructor + exact message) from (status, detail)
+inline DecompressionError error_from_status(const ByteString &stream, int32_t status, const uint32_t det[2])
+{
+    DecompressionError e;
+    e.constructor = constructor_of(status);
+    e.status = status;
+    e.detail[0] = det[0];
+    e.detail[1] = det[1];
+    char buf[256];
+    pzg_error_message((const uint8_t *)stream.data(), stream.size(), status, det, buf, sizeof buf);
+    const std::string text(buf);
+    DecompressionError p = e;  // p.show() with an empty message is just the constructor's prefix
+    p.message.clear();
+    const std::string prefix = p.show();
+    e.message = (!prefix.empty() && text.compare(0, prefix.size(), prefix) == 0) ? text.substr(prefix.size()) : text;
+    return e;
+}
+
+inline uint64_t align16(uint64_t x) { return (x + 15u) & ~(uint64_t)15u; }
+
+}  // namespace detail
+
+// One pzg_ctx (HIP device + stream + staging arenas); the library locks it internally.
+class Context {
+  public:
+    explicit Context(int device = 0)
+    {
+        int rc = pzg_init(device, &h_);
+        if (rc != PZG_RC_OK) throw std::runtime_error(std::string("pzg_init: ") + pzg_strerror(rc) + " (there is no CPU fallback)");
+    }
+    ~Context()
+    {
+        if (h_) pzg_shutdown(h_);
+    }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    pzg_ctx *handle() const { return h_; }
+
+    static Context &shared()
+    {
+        static Context c(0);
+        return c;
+    }
+
+  private:
+    pzg_ctx *h_ = nullptr;
+};
+
+// Zlib.hs:46-49: `Done` with whole unread chunks left is Left "Finished with data remaining."; trailing
+// bytes inside the last chunk handed over are silently ignored.
+inline Either apply_chunk_rule(const LazyByteString &chunks, uint64_t in_used, ByteString data)
+{
+    uint64_t cum = 0;
+    size_t loaded = 0;
+    for (const auto &c : chunks) {
+        if (cum >= in_used) break;
+        cum += c.size();
+        ++loaded;
+    }
+    if (loaded < chunks.size()) {
+        DecompressionError e;
+        e.constructor = DecompressionError::DecompressionError_;
+        e.message = "Finished with data remaining.";
+        e.status = PZG_E_DATA_REMAINING;
+        return Either::Left(e);
+    }
+    return Either::Right(std::move(data));
+}
+
+// decompressMany: every stream decoded by its own wavefront in one launch.  zlib streams do not carry
+// their decoded size, so each stream gets a capacity (size_hint[i], or a guess) and the streams that
+// report PZG_E_OUT_TOO_SMALL are relaunched once with the exact size the kernel measured.
+inline std::vector<Either> decompressMany(const std::vector<LazyByteString> &inputs, Context &ctx = Context::shared(),
+                                          const std::vector<uint64_t> *size_hint = nullptr)
+{
+    const size_t n = inputs.size();
+    std::vector<Either> results(n);
+    std::vector<ByteString> flat(n);
+    std::vector<uint64_t> caps(n);
+    for (size_t i = 0; i < n; ++i) {
+        flat[i] = toStrict(inputs[i]);
+        caps[i] = size_hint ? (*size_hint)[i] : (flat[i].size() * 4 > 65536 ? flat[i].size() * 4 : 65536);
+    }
+    std::vector<size_t> todo(n);
+    for (size_t i = 0; i < n; ++i) todo[i] = i;
+    for (int attempt = 0; attempt < 2 && !todo.empty(); ++attempt) {
+        const size_t m = todo.size();
+        std::vector<uint64_t> in_off(m), in_len(m), out_off(m), out_cap(m), out_len(m), in_used(m);
+        std::vector<int32_t> status(m, -1);
+        std::vector<uint32_t> det(2 * m), adler(m);
+        uint64_t ipos = 0, opos = 0;
+        for (size_t k = 0; k < m; ++k) {  // 16-byte aligned extents: the wide store path
+            in_off[k] = ipos;
+            out_off[k] = opos;
+            in_len[k] = flat[todo[k]].size();
+            out_cap[k] = caps[todo[k]];
+            ipos += detail::align16(in_len[k]);
+            opos += detail::align16(out_cap[k]);
+        }
+        std::vector<uint8_t> in_buf(ipos + 16), out_buf(opos + 16);
+        for (size_t k = 0; k < m; ++k)
+            if (in_len[k]) memcpy(in_buf.data() + in_off[k], flat[todo[k]].data(), in_len[k]);
+        int rc = pzg_decompress_many(ctx.handle(), in_buf.data(), in_off.data(), in_len.data(), out_buf.data(), out_off.data(),
+                                     out_cap.data(), out_len.data(), status.data(), det.data(), in_used.data(), adler.data(),
+                                     (uint32_t)m, 0);
+        if (rc != PZG_RC_OK) throw std::runtime_error(std::string("pzg_decompress_many: ") + pzg_last_error(ctx.handle()));
+        std::vector<size_t> retry;
+        for (size_t k = 0; k < m; ++k) {
+            const size_t i = todo[k];
+            if (status[k] == PZG_OK) {
+                results[i] = apply_chunk_rule(inputs[i], in_used[k], ByteString((const char *)out_buf.data() + out_off[k], out_len[k]));
+            } else if (status[k] == PZG_E_OUT_TOO_SMALL && attempt == 0) {
+                caps[i] = out_len[k];
+                retry.push_back(i);
+            } else {
+                results[i] = Either::Left(detail::error_from_status(flat[i], status[k], &det[2 * k]));
+            }
+        }
+        todo.swap(retry);
+    }
+    return results;
+}
+
+// Codec.Compression.Zlib.decompress (Zlib.hs:32-51): pure, strict, same Left values
+inline Either decompress(const LazyByteString &ifile, Context &ctx = Context::shared())
+{
+    return decompressMany({ifile}, ctx)[0];
+}
+
+// ---- ZlibDecoder (Monad.hs:163-167) and decompressIncremental (Zlib.hs:29-30) -------------------------
+//   data ZlibDecoder s = NeedMore (ByteString -> ST s (ZlibDecoder s)) | Chunk ByteString (ST s (ZlibDecoder s))
+//                      | Done | DecompError DecompressionError
+// A wavefront cannot be suspended mid-stream, so this decoder buffers what it is fed and re-decodes the
+// accumulated input on the GPU at each feed; it answers NeedMore while the stream is incomplete and
+// then hands the output out as 32,768-byte Chunks followed by the remainder, the sizes
+// moveWindow/finalize produce (Monad.hs:338-358, OutputWindow.hs:42-60).  No CPU inflate anywhere.
+class ZlibDecoder {
+  public:
+    enum State { NeedMore, Chunk, Done, DecompError };
+    State state() const { return state_; }
+
+    // NeedMore f: apply f to the next input chunk
+    void feed(const ByteString &chunk)
+    {
+        if (state_ != NeedMore) throw std::logic_error("feed: the decoder is not in NeedMore");
+        if (chunk.empty()) return;  // S.uncons = Nothing: ask again (Monad.hs:185-197)
+        acc_ += chunk;
+        Either r = decompress(fromStrict(acc_), *ctx_);
+        if (!r.is_right) {
+            if (r.left.status == PZG_E_TRUNCATED) return;  // the stream is not complete yet
+            error_ = r.left;
+            state_ = DecompError;
+            return;
+        }
+        out_ = std::move(r.right);
+        pos_ = 0;
+        advance();
+    }
+    // Chunk c m: the chunk, then run the continuation m
+    const ByteString &chunk() const { return cur_; }
+    void next()
+    {
+        if (state_ != Chunk) throw std::logic_error("next: the decoder is not in Chunk");
+        advance();
+    }
+    const DecompressionError &error() const { return error_; }
+
+    explicit ZlibDecoder(Context &ctx = Context::shared()) : ctx_(&ctx) {}
+
+  private:
+    static constexpr size_t kExcess = 32768;  // OutputWindow.hs:42-43 excessChunkSize
+    void advance()
+    {
+        if (final_published_) {
+            state_ = Done;
+            return;
+        }
+        const size_t left = out_.size() - pos_;
+        if (left >= 2 * kExcess) {  // emitExcess: a 32 KiB piece whenever >= 64 KiB are buffered
+            cur_ = out_.substr(pos_, kExcess);
+            pos_ += kExcess;
+        } else {  // finalizeWindow publishes whatever is left (possibly empty)
+            cur_ = out_.substr(pos_);
+            pos_ = out_.size();
+            final_published_ = true;
+        }
+        state_ = Chunk;
+    }
+    Context *ctx_;
+    State state_ = NeedMore;
+    ByteString acc_, out_, cur_;
+    size_t pos_ = 0;
+    bool final_published_ = false;
+    DecompressionError error_;
+};
+
+inline ZlibDecoder decompressIncremental(Context &ctx = Context::shared()) { return ZlibDecoder(ctx); }
+
+}  // namespace Zlib
+}  // namespace Compression
+}  // namespace Codec

@@ -90,3 +90,19 @@ def test_either_and_error_types():
     assert P.ChecksumError("c").show().startswith("Checksum error: ")
     assert P.FormatError("f").show().startswith("Block format error: ")
     assert P.HuffmanTreeError("h").show().startswith("Huffman tree manipulation error: ")
+
+
+def test_cxx_module_mirror_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """pure_zlib_amd/cxx/codec_compression_zlib.hpp (the C++ host mirror of the reference's module) compiles
+    against include/pzg.h and links libpzg.so; with no GPU the first call throws (no CPU fallback exists)."""
+    import subprocess
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_mirror")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", os.path.join(root, "tests", "cxx", "test_mirror.cpp"),
+                           "-o", exe, "-L" + os.path.join(root, "pure_zlib_amd"), "-lpzg",
+                           "-Wl,-rpath," + os.path.join(root, "pure_zlib_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    if torch.cuda.is_available():
+        return  # the GPU suite runs it for real
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "ref")], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "no CPU fallback" in out.stderr

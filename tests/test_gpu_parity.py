@@ -306,3 +306,15 @@ def test_long_codes_second_level_tables(ctx, oracle):
         else:
             err = Z.error_from_status(bad[k], int(status[k]), detail[k])
             assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())
+
+
+def test_cxx_module_mirror_reads_like_the_reference_tests():
+    """The C++ host mirror of Codec.Compression.Zlib (pure_zlib_amd/cxx/codec_compression_zlib.hpp) driven by
+    tests/cxx/test_mirror.cpp: Test.hs's nine cases, decompressMany, the chunk rule, error values, the incremental decoder."""
+    exe = os.path.join(ROOT, "tests", "cxx", "test_mirror")
+    src = os.path.join(ROOT, "tests", "cxx", "test_mirror.cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", src, "-o", exe, "-L" + os.path.join(ROOT, "pure_zlib_amd"),
+                           "-lpzg", "-Wl,-rpath," + os.path.join(ROOT, "pure_zlib_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "ref")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(" OK") == 18 and "0 failure(s)" in out.stdout
