@@ -73,6 +73,9 @@ def build_pool(args):
         else:
             t = corpus.zipf_text(args.blob_bytes, seed)
             z = zlib.compress(t, args.level)
+        if args.gzip:  # same DEFLATE body, gzip header and CRC-32 + ISIZE trailer instead of the zlib ones
+            import struct
+            z = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + z[2:-4] + struct.pack("<II", zlib.crc32(t), len(t) & 0xffffffff)
         texts.append(t)
         zs.append(z)
     return texts, zs
@@ -93,6 +96,7 @@ def main():
     ap.add_argument("--ring-bits", type=int, default=0, help="LDS ring size class 11..15 (0 = library default); 15 = the whole 32 KiB window in LDS")
     ap.add_argument("--no-ab", action="store_true", help="skip the secondary measurement of the pure 32 KiB LDS-ring variant")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--gzip", action="store_true", help="diagnostic: the same payloads as RFC 1952 members (extension; CRC-32 pass on the device)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     args = ap.parse_args()
 
@@ -159,7 +163,7 @@ def main():
         ctx.decompress_many_device(d_in.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), d_out.data_ptr(),
                                    d_out_off.data_ptr(), d_out_cap.data_ptr(), d_out_len.data_ptr(),
                                    d_status.data_ptr(), d_detail.data_ptr(), d_in_used.data_ptr(), d_adler.data_ptr(),
-                                   n, sync=False)
+                                   n, sync=False, gzip=args.gzip)
 
     def barrier():
         if world > 1:
@@ -189,7 +193,7 @@ def main():
     adler = d_adler.cpu().numpy().view(np.uint32)
     bit_exact = None
     if not args.no_verify:
-        exp_adler = np.array([zlib.adler32(t) for t in texts], dtype=np.uint32)[pick]
+        exp_adler = np.array([(zlib.crc32(t) if args.gzip else zlib.adler32(t)) for t in texts], dtype=np.uint32)[pick]
         ok = bool((status == 0).all() and (out_len == out_cap).all() and (adler == exp_adler).all()
                   and (d_in_used.cpu().numpy() == in_len).all())
         if ok and len(set(dec_len.tolist())) == 1:
@@ -270,6 +274,7 @@ def main():
                 "decompressed_MiB_per_gpu": round(int(out_cap.sum()) / 2**20, 1),
                 "parallelism": f"shard{world}" if world > 1 else "single",
                 "ring_bits": ring_bits,
+                **({"container": "gzip members (extension): CRC-32 + ISIZE verified by a second kernel"} if args.gzip else {}),
                 "window": "32 KiB LDS ring" if ring_bits == 15 else f"{2**ring_bits // 1024} KiB LDS near ring + far back-references from the stream's flushed output (HBM/L2)",
                 "verified": "every stream: status, length, in_used, Adler-32 and full byte compare" if bit_exact is not None else "skipped",
             },

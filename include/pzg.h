@@ -62,6 +62,10 @@ extern "C" {
 #define PZG_E_OUT_TOO_SMALL      14  /* not a reference outcome: out_len[i] holds the size needed */
 #define PZG_E_DATA_REMAINING     15  /* DecompressionError "Finished with data remaining." -- produced by the host
                                         mirror from in_used[] and the caller's chunking (Zlib.hs:48-49), never by the kernel */
+/* PZG_GZIP only (extension, no reference counterpart): */
+#define PZG_E_GZIP_HEADER        18  /* "Header error: gzip: ..."; d0 = 1 bad magic, 2 method != 8, 3 reserved flag bits, 4 header CRC16 */
+#define PZG_E_GZIP_ISIZE         19  /* "Checksum error: gzip: length mismatch: <d0> != <d1>" (ISIZE vs bytes produced mod 2^32);
+                                      * a CRC-32 mismatch is PZG_E_CHECKSUM.  Not checked for PZG_E_OUT_TOO_SMALL streams. */
 
 /* tree ids in detail[2*i] of PZG_E_HUFF_BUILD */
 #define PZG_TREE_CODELEN 0
@@ -71,6 +75,8 @@ extern "C" {
 /* ---- flags ------------------------------------------------------------------- */
 #define PZG_DEVICE_PTRS  1u  /* every pointer argument is device memory on the context's device */
 #define PZG_ASYNC        2u  /* enqueue only (requires PZG_DEVICE_PTRS); caller calls pzg_sync() */
+#define PZG_GZIP         4u  /* EXTENSION (the reference has no gzip: README.md:42-50 TODO): every stream is
+                              * one RFC 1952 member (gzip header, deflate, CRC-32 + ISIZE); adler[] then holds the CRC-32 */
 
 typedef struct pzg_ctx pzg_ctx;
 

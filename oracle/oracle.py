@@ -103,6 +103,21 @@ def decompress_chunks(chunks, out_cap: int = None, flags: int = 0):
     return r, out.raw[: min(r.out_len, out_cap)]
 
 
+F_REF_CHUNK_BUG, F_GZIP = 1, 2
+
+
+def gzip_decompress(data: bytes, out_cap: int = None):
+    """One RFC 1952 member (extension); Result.adler holds the CRC-32."""
+    return decompress_chunks([data] if data else [], out_cap, F_GZIP)
+
+
+def crc32(data: bytes, init: int = 0) -> int:
+    L = lib()
+    L.pzo_crc32.restype = C.c_uint32
+    L.pzo_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64]
+    return L.pzo_crc32(init, data, len(data))
+
+
 def adler32(data: bytes, init: int = 1) -> int:
     return lib().pzo_adler32(init, data, len(data))
 

@@ -155,6 +155,7 @@ typedef struct {
     int bitno;               /* dcsNextBitNo */
     uint8_t cur;             /* dcsCurByte */
     uint32_t a, b;           /* dcsAdler32 */
+    uint32_t crc;            /* PZO_F_GZIP only: CRC-32 register over the bytes produced (extension) */
     uint8_t *out;
     uint64_t cap;
     uint64_t total;          /* bytes produced so far */
@@ -318,8 +319,26 @@ static void ow_advance(dstate *s, uint64_t n)
     s->ow_next += n;
 }
 
+/* RFC 1952 section 8, bit by bit (extension: gzip is not in the reference) */
+static uint32_t crc32_byte(uint32_t reg, uint8_t v)
+{
+    int k;
+    reg ^= v;
+    for (k = 0; k < 8; k++) reg = (reg >> 1) ^ (0xedb88320u & (0u - (reg & 1u)));
+    return reg;
+}
+
+uint32_t pzo_crc32(uint32_t crc, const uint8_t *buf, uint64_t len)
+{
+    uint32_t reg = ~crc;
+    uint64_t i;
+    for (i = 0; i < len; i++) reg = crc32_byte(reg, buf[i]);
+    return ~reg;
+}
+
 static void put_byte(dstate *s, uint8_t v)
 {
+    if (s->flags & PZO_F_GZIP) s->crc = crc32_byte(s->crc, v);
     if (s->total < s->cap) s->out[s->total] = v;
     s->win[s->total & 65535u] = v;
     s->total++;
@@ -611,6 +630,65 @@ static void build_fixed(dstate *s)
 }
 
 /* Zlib.hs:53-69 inflateWithHeaders + Deflate.hs:39-63 inflate/checkChecksum */
+/* RFC 1952 member: header (2.3), deflate, CRC32 + ISIZE little-endian.  Extension, see PZO_F_GZIP. */
+static void inflate_gzip_member(dstate *s)
+{
+    uint32_t hreg = 0xffffffffu, id1, id2, cm, flg, i;
+    char m[128];
+#define GZ_NEXT(dst) do { uint32_t b_ = next_byte(s); hreg = crc32_byte(hreg, (uint8_t)b_); (dst) = b_; } while (0)
+    GZ_NEXT(id1);
+    GZ_NEXT(id2);
+    if (id1 != 0x1f || id2 != 0x8b) raise_err(s, PZO_E_GZIP_HEADER, 1, (id1 << 8) | id2, "Header error: gzip: bad magic");
+    GZ_NEXT(cm);
+    if (cm != 8) {
+        snprintf(m, sizeof m, "Header error: gzip: bad compression method: %u", cm);
+        raise_err(s, PZO_E_GZIP_HEADER, 2, cm, m);
+    }
+    GZ_NEXT(flg);
+    if (flg & 0xe0) raise_err(s, PZO_E_GZIP_HEADER, 3, flg, "Header error: gzip: reserved flag bits set");
+    for (i = 0; i < 6; i++) { uint32_t skip; GZ_NEXT(skip); (void)skip; } /* MTIME, XFL, OS */
+    if (flg & 4) { /* FEXTRA */
+        uint32_t lo, hi, xlen;
+        GZ_NEXT(lo);
+        GZ_NEXT(hi);
+        xlen = lo | (hi << 8);
+        for (i = 0; i < xlen; i++) { uint32_t skip; GZ_NEXT(skip); (void)skip; }
+    }
+    if (flg & 8) { uint32_t c; do { GZ_NEXT(c); } while (c != 0); }  /* FNAME */
+    if (flg & 16) { uint32_t c; do { GZ_NEXT(c); } while (c != 0); } /* FCOMMENT */
+    if (flg & 2) { /* FHCRC: the low 16 bits of the CRC-32 of the header so far */
+        uint32_t want = ~hreg & 0xffffu, lo = next_byte(s), hi = next_byte(s), got = lo | (hi << 8);
+        if (got != want) {
+            snprintf(m, sizeof m, "Header error: gzip: header crc mismatch: %x != %x", got, want);
+            raise_err(s, PZO_E_GZIP_HEADER, 4, got, m);
+        }
+    }
+#undef GZ_NEXT
+    build_fixed(s);
+    s->crc = 0xffffffffu;
+    for (;;) {
+        int is_final = inflate_block(s);
+        move_window(s);
+        if (is_final) break;
+    }
+    {
+        uint32_t ours = ~s->crc, theirs, isize;
+        advance_to_byte(s);
+        theirs = next_word16(s);
+        theirs |= next_word16(s) << 16;
+        isize = next_word16(s);
+        isize |= next_word16(s) << 16;
+        if (theirs != ours) {
+            snprintf(m, sizeof m, "Checksum error: checksum mismatch: %x != %x", theirs, ours);
+            raise_err(s, PZO_E_CHECKSUM, theirs, ours, m);
+        }
+        if (isize != (uint32_t)s->total) {
+            snprintf(m, sizeof m, "Checksum error: gzip: length mismatch: %u != %u", isize, (uint32_t)s->total);
+            raise_err(s, PZO_E_GZIP_ISIZE, isize, (uint32_t)s->total, m);
+        }
+    }
+}
+
 static void inflate_with_headers(dstate *s)
 {
     uint32_t cmf = next_byte(s);
@@ -672,8 +750,10 @@ int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t
     s->ow_next = 0;
     s->flags = flags;
     s->res = res;
+    s->crc = 0xffffffffu;
     if (setjmp(s->jb) == 0) {
-        inflate_with_headers(s);
+        if (flags & PZO_F_GZIP) inflate_gzip_member(s);
+        else inflate_with_headers(s);
         /* Zlib.hs:46-49: Done with chunks left over is an error, Done with none is Right */
         if (s->chunk_next < s->nchunks) {
             res->status = PZO_E_DATA_REMAINING;
@@ -684,7 +764,7 @@ int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t
             snprintf(res->message, sizeof res->message, "(not a reference outcome) output buffer too small");
         }
     }
-    res->adler = (s->b << 16) | s->a;
+    res->adler = (flags & PZO_F_GZIP) ? ~s->crc : ((s->b << 16) | s->a);
     res->out_len = s->total;
     res->in_used = (uint64_t)(s->p - in);
     return res->status;

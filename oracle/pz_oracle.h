@@ -50,7 +50,12 @@ enum {
     PZO_E_OUT_TOO_SMALL = 14,   /* not a reference outcome: caller's buffer too small          */
     PZO_E_DATA_REMAINING = 15,  /* DecompressionError "Finished with data remaining."          Zlib.hs:48-49 */
     PZO_E_HUFF_ADVANCE_VALUE = 16,/* HuffmanTreeError "Tried to advance value!" (unreachable)  HuffmanTree.hs:77 */
-    PZO_E_BAD_CODELEN_SYMBOL = 17 /* DecompressionError "Unexpected code: n" (unreachable)      Deflate.hs:148-149 */
+    PZO_E_BAD_CODELEN_SYMBOL = 17,/* DecompressionError "Unexpected code: n" (unreachable)      Deflate.hs:148-149 */
+    /* RFC 1952 members (PZO_F_GZIP): an EXTENSION the reference does not have (README.md:42-50 lists gzip as
+     * a TODO).  Restated from the RFC, pinned against system zlib (wbits = 31), not
+     * against pure-zlib. */
+    PZO_E_GZIP_HEADER = 18,     /* detail0: 1 magic, 2 method != 8, 3 reserved FLG bits, 4 header CRC16 */
+    PZO_E_GZIP_ISIZE = 19       /* detail0 = ISIZE in the trailer, detail1 = bytes produced mod 2^32 (CRC mismatch is PZO_E_CHECKSUM) */
 };
 
 /* detail0 of PZO_E_HUFF_BUILD: which tree failed (low byte) and which message (next byte) */
@@ -69,7 +74,8 @@ enum {
 
 /* flags for pzo_decompress_chunks */
 enum {
-    PZO_F_REF_CHUNK_BUG = 1u  /* replicate Monad.hs:280-293 literally (stored block ending exactly at a chunk end) */
+    PZO_F_REF_CHUNK_BUG = 1u, /* replicate Monad.hs:280-293 literally (stored block ending exactly at a chunk end) */
+    PZO_F_GZIP = 2u           /* the input is one RFC 1952 member: gzip header, deflate, CRC-32 + ISIZE; res->adler holds the CRC-32 */
 };
 
 typedef struct pzo_result {
@@ -96,6 +102,9 @@ int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t
 
 /* Adler32.hs:19-57.  `adler` is a finalized value ((b<<16)|a); pass 1 to start. */
 uint32_t pzo_adler32(uint32_t adler, const uint8_t *buf, uint64_t len);
+
+/* CRC-32 (RFC 1952 section 8; reflected 0xedb88320), `crc` = the value so far, 0 to start.  Extension, see PZO_F_GZIP. */
+uint32_t pzo_crc32(uint32_t crc, const uint8_t *buf, uint64_t len);
 
 /* Deflate.hs:261-288 computeCodeValues.  Input n (symbol,length) pairs in any order;
  * output triples ascending by symbol with zero lengths dropped.  Returns count. */

@@ -27,9 +27,12 @@ E_BAD_LITLEN_SYMBOL = 12
 E_BAD_DIST_SYMBOL = 13
 E_OUT_TOO_SMALL = 14
 E_DATA_REMAINING = 15
+E_GZIP_HEADER = 18  # PZG_GZIP only (extension)
+E_GZIP_ISIZE = 19
 
 DEVICE_PTRS = 1
 ASYNC = 2
+GZIP = 4  # extension: streams are RFC 1952 members; adler[] holds the CRC-32
 OPT_RING_BITS = 1
 DEFAULT_RING_BITS = 11
 

@@ -59,6 +59,8 @@ enum : int32_t {
     ST_BAD_LITLEN_SYMBOL = 12,
     ST_BAD_DIST_SYMBOL = 13,
     ST_OUT_TOO_SMALL = 14,
+    ST_GZIP_HEADER = 18,  // extension (RFC 1952): detail0 = 1 magic, 2 method, 3 reserved flag bits, 4 header CRC16
+    ST_GZIP_ISIZE = 19,   // extension: detail0 = ISIZE in the trailer, detail1 = bytes produced mod 2^32
     ST_RETRY_FULL_RING = 100  // internal: a small-ring launch met an output larger than its capacity; the 32 KiB ring kernel redoes the stream
 };
 
@@ -280,7 +282,8 @@ struct BitReader {
 };
 
 // ---- decoder state (all wave-uniform) -----------------------------------------------------------
-template <int RING_BITS>
+// GZIP: the streams are RFC 1952 members (an extension; its own kernel instances, so the zlib ones carry none of it)
+template <int RING_BITS, bool GZIP = false>
 struct Decoder {
     static constexpr uint32_t RING = 1u << RING_BITS;
     static constexpr uint32_t RMASK = RING - 1u;
@@ -1401,6 +1404,7 @@ struct Decoder {
     // ---- Zlib.hs:53-69 inflateWithHeaders + Deflate.hs:39-63 inflate ---------------------------------
     PZG_FN void run(const uint8_t *in_, uint64_t in_len_, uint8_t *out_, uint64_t cap_, StreamResult *res)
     {
+
         in = in_;
         in_len = in_len_;
         out = out_;
@@ -1439,8 +1443,62 @@ struct Decoder {
         res->in_used = used;
     }
 
+    // ---- RFC 1952 (extension; the reference lists gzip as a TODO, README.md:42-50) -------------------
+    PZG_FN int gz_byte(uint32_t &b, uint32_t &hreg)
+    {
+        if (br.avail() < 8) return fail(ST_TRUNCATED, 0, 0);
+        b = br.peek32() & 0xffu;
+        br.drop(8);
+        uint32_t r = hreg ^ b;  // CRC-32 of the header bytes, for FHCRC
+#pragma nounroll
+        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (0xedb88320u & (0u - (r & 1u)));
+        hreg = r;
+        return ST_OK;
+    }
+    PZG_FN int gzip_header()
+    {
+        uint32_t hreg = 0xffffffffu, id1 = 0, id2 = 0, cm = 0, flg = 0, b = 0;
+        if (int st = gz_byte(id1, hreg)) return st;
+        if (int st = gz_byte(id2, hreg)) return st;
+        if (id1 != 0x1fu || id2 != 0x8bu) return fail(ST_GZIP_HEADER, 1, (id1 << 8) | id2);
+        if (int st = gz_byte(cm, hreg)) return st;
+        if (cm != 8u) return fail(ST_GZIP_HEADER, 2, cm);
+        if (int st = gz_byte(flg, hreg)) return st;
+        if (flg & 0xe0u) return fail(ST_GZIP_HEADER, 3, flg);
+#pragma nounroll
+        for (int k = 0; k < 6; ++k)  // MTIME, XFL, OS
+            if (int st = gz_byte(b, hreg)) return st;
+        if (flg & 4u) {  // FEXTRA
+            uint32_t lo = 0, hi = 0;
+            if (int st = gz_byte(lo, hreg)) return st;
+            if (int st = gz_byte(hi, hreg)) return st;
+#pragma nounroll
+            for (uint32_t k = 0; k < (lo | (hi << 8)); ++k)
+                if (int st = gz_byte(b, hreg)) return st;
+        }
+#pragma nounroll
+        for (uint32_t field = 8u; field <= 16u; field <<= 1)  // FNAME, FCOMMENT: zero-terminated
+            if (flg & field) {
+                do {
+                    if (int st = gz_byte(b, hreg)) return st;
+                } while (b != 0u);
+            }
+        if (flg & 2u) {  // FHCRC: the low 16 bits of the CRC-32 of the header so far
+            const uint32_t want = ~hreg & 0xffffu;
+            uint32_t lo = 0, hi = 0, dummy = 0;
+            if (int st = gz_byte(lo, dummy)) return st;
+            if (int st = gz_byte(hi, dummy)) return st;
+            if ((lo | (hi << 8)) != want) return fail(ST_GZIP_HEADER, 4, lo | (hi << 8));
+        }
+        return ST_OK;
+    }
+
     PZG_FN int decode()
     {
+        if (GZIP) {
+            if (int st = gzip_header()) return st;
+            return blocks_and_trailer();
+        }
         // Zlib.hs:55-67: CMF, FLG; FCHECK, then CM, then CINFO
         if (br.avail() < 16) return fail(ST_TRUNCATED, 0, 0);
         const uint32_t hw = br.peek32();
@@ -1453,6 +1511,11 @@ struct Decoder {
             if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
             br.drop(32);
         }
+        return blocks_and_trailer();
+    }
+
+    PZG_FN int blocks_and_trailer()
+    {
         for (;;) {  // Deflate.hs:45-50 go
             pin_uniform();
             const uint32_t block_bit = (uint32_t)stream_bit_pos();
@@ -1484,6 +1547,14 @@ struct Decoder {
         // Deflate.hs:52-63 checkChecksum: align, fold the rest of the window, compare big-endian
         flush_to(op);
         br.align_to_byte();
+        if (GZIP) {  // RFC 1952: CRC-32 then ISIZE, little-endian; crc32_verify_kernel checks both against the output
+            if (br.avail() < 64) return fail(ST_TRUNCATED, 0, 0);
+            detail0 = br.peek32();  // (a successful stream has no other use for the two detail words)
+            br.drop(32);
+            detail1 = br.peek32();
+            br.drop(32);
+            return ST_OK;
+        }
         if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
         const uint32_t t = br.peek32();
         const uint32_t theirs = (t << 24) | ((t & 0xff00u) << 8) | ((t >> 8) & 0xff00u) | (t >> 24);

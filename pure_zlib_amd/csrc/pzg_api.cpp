@@ -33,7 +33,7 @@ struct pzg_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::mutex mu;
-    Arena a_in, a_out, a_meta, a_adler;
+    Arena a_in, a_out, a_meta, a_adler, a_gz;
     void *h_stage = nullptr;  // pinned host staging for the host-pointer path
     size_t h_stage_cap = 0;
     std::string last_error;
@@ -140,7 +140,7 @@ void pzg_shutdown(pzg_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (Arena *a : {&ctx->a_in, &ctx->a_out, &ctx->a_meta, &ctx->a_adler})
+    for (Arena *a : {&ctx->a_in, &ctx->a_out, &ctx->a_meta, &ctx->a_adler, &ctx->a_gz})
         if (a->p) (void)hipFree(a->p);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
@@ -201,7 +201,13 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     if (flags & PZG_DEVICE_PTRS) {
         if (!out_base) return PZG_RC_BAD_ARG;
         pzg::InflateArgs a{in_base, in_off, in_len, out_base, out_off, out_cap, out_len,
-                           status,  detail, in_used, adler,   nullptr, nullptr, nullptr, n};
+                           status,  detail, in_used, adler,   nullptr, nullptr, nullptr, n, 0, nullptr};
+        if (flags & PZG_GZIP) {
+            int rcg = arena_reserve(ctx, ctx->a_gz, 8 * (size_t)n);
+            if (rcg != PZG_RC_OK) return rcg;
+            a.gzip = 1;
+            a.gz_expect = (uint32_t *)ctx->a_gz.p;
+        }
 #if defined(PZG_PROFILE)
         a.prof_out = (uint64_t *)ctx->prof_buf;
 #endif
@@ -260,6 +266,11 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     a.prof_out = (uint64_t *)ctx->prof_buf;
 #endif
     a.n = n;
+    if (flags & PZG_GZIP) {
+        if ((rc = arena_reserve(ctx, ctx->a_gz, 8 * (size_t)n)) != PZG_RC_OK) return rc;
+        a.gzip = 1;
+        a.gz_expect = (uint32_t *)ctx->a_gz.p;
+    }
     if ((rc = launch_timed(ctx, a)) != PZG_RC_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_len, a.out_len, 8 * N, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(status, a.status, 4 * N, hipMemcpyDeviceToHost, s));

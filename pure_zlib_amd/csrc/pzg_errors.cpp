@@ -187,6 +187,13 @@ extern "C" int pzg_error_message(const uint8_t *in, uint64_t in_len, int32_t sta
         break;
     case PZG_E_OUT_TOO_SMALL: snprintf(buf, buf_len, "(not a reference outcome) output buffer too small"); break;
     case PZG_E_DATA_REMAINING: snprintf(buf, buf_len, "Decompression error: Finished with data remaining."); break;
+    case PZG_E_GZIP_HEADER:  // extension (RFC 1952): no reference text exists for these
+        if (d0 == 1) snprintf(buf, buf_len, "Header error: gzip: bad magic");
+        else if (d0 == 2) snprintf(buf, buf_len, "Header error: gzip: bad compression method: %u", d1);
+        else if (d0 == 3) snprintf(buf, buf_len, "Header error: gzip: reserved flag bits set");
+        else snprintf(buf, buf_len, "Header error: gzip: header crc mismatch");
+        break;
+    case PZG_E_GZIP_ISIZE: snprintf(buf, buf_len, "Checksum error: gzip: length mismatch: %u != %u", d0, d1); break;
     default: snprintf(buf, buf_len, "unknown status %d", status); break;
     }
     return (int)strlen(buf);

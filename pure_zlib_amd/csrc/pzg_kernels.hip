@@ -35,7 +35,7 @@ constexpr uint32_t waves_per_cu()
     return by_lds < by_vgpr ? by_lds : by_vgpr;
 }
 
-template <int RING_BITS, bool FIXUP>
+template <int RING_BITS, bool FIXUP, bool GZIP = false>
 __global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(InflateArgs a)
 {
     __shared__ WaveLds<RING_BITS> lds;
@@ -56,19 +56,24 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(
 #endif
         // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
         if (FIXUP && a.status[i] != ST_RETRY_FULL_RING) continue;
-        Decoder<RING_BITS> dec(lds);
+        Decoder<RING_BITS, GZIP> dec(lds);
         StreamResult r;
         dec.run(a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i], &r);
         if (threadIdx.x == 0) {
             a.status[i] = r.status;
             if (!FIXUP && r.status == ST_RETRY_FULL_RING) atomicAdd(a.counter + 1, 1u);
             a.out_len[i] = r.out_len;
+            const bool gz_ok = GZIP && r.status == ST_OK;  // then the detail words carry the trailer's CRC-32 and ISIZE
             if (a.detail) {
-                a.detail[2 * (size_t)i] = r.detail0;
-                a.detail[2 * (size_t)i + 1] = r.detail1;
+                a.detail[2 * (size_t)i] = gz_ok ? 0u : r.detail0;
+                a.detail[2 * (size_t)i + 1] = gz_ok ? 0u : r.detail1;
             }
             if (a.in_used) a.in_used[i] = r.in_used;
-            if (a.adler) a.adler[i] = r.adler;
+            if (a.adler) a.adler[i] = GZIP ? 0u : r.adler;  // gzip: crc32_verify_kernel fills in the CRC-32
+            if (GZIP) {
+                a.gz_expect[2 * (size_t)i] = r.detail0;
+                a.gz_expect[2 * (size_t)i + 1] = r.detail1;
+            }
 #if defined(PZG_PROFILE)
             // diagnostic build: the 16 phase counters of stream i go to prof_out[16*i ..]
             if (a.prof_out)
@@ -76,6 +81,96 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(
 #endif
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CRC-32 (RFC 1952 section 8) of each decoded gzip member against its trailer: an extension (the reference has
+// no gzip).  One wave per stream.  The stream is cut into 64 equal slices by padding
+// it at the FRONT with zero bytes (a zero register stays zero over zero bytes, so the padding is free);
+// lane l runs slice l through four byte-indexed tables in LDS (slicing-by-4), starting from 0xffffffff
+// in the lane that holds the first real byte and from 0 in the others; the 64 registers are then folded
+// pairwise, R_left * x^(8 * slice * 2^level) + R_right over GF(2) modulo the CRC polynomial.
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)  // reflected bit order, poly 0xedb88320
+{
+    uint32_t p = 0;
+#pragma nounroll
+    for (int i = 0; i < 32; ++i) {
+        p ^= b & (0u - ((a >> (31 - i)) & 1u));
+        b = (b >> 1) ^ (0xedb88320u & (0u - (b & 1u)));
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(64) void crc32_verify_kernel(InflateArgs a)
+{
+    __shared__ uint32_t T[4][256];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t v = lane; v < 256u; v += 64u) {
+        uint32_t r = v;
+        for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (0xedb88320u & (0u - (r & 1u)));
+        T[0][v] = r;
+    }
+    __syncthreads();
+    for (uint32_t v = lane; v < 256u; v += 64u) {
+        uint32_t r = T[0][v];
+        for (int k = 1; k < 4; ++k) {
+            r = (r >> 8) ^ T[0][r & 0xffu];
+            T[k][v] = r;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+        if (a.status[i] != ST_OK) continue;  // (also: output larger than its capacity -- nothing stored to check)
+        const uint64_t len = a.out_len[i];
+        const uint8_t *p = a.out_base + a.out_off[i];
+        const uint64_t slice = ((len + 63u) / 64u + 3u) & ~(uint64_t)3u;  // bytes per lane, a multiple of 4
+        const uint64_t pad = 64u * slice - len;                           // zero bytes in front
+        const uint64_t lo = (uint64_t)lane * slice, hi = lo + slice;      // this lane's span of the padded stream
+        uint32_t reg = 0;
+        if (hi > pad) {
+            uint64_t q = lo > pad ? lo - pad : 0u;  // first real byte of the span
+            const uint64_t qe = hi - pad;
+            if (lo <= pad) reg = 0xffffffffu;       // the stream starts in this span
+            for (; q < qe && ((qe - q) & 3u); ++q) reg = (reg >> 8) ^ T[0][(reg ^ p[q]) & 0xffu];
+            for (; q < qe; q += 4) {
+                uint32_t w;
+                __builtin_memcpy(&w, p + q, 4);
+                reg ^= w;
+                reg = T[3][reg & 0xffu] ^ T[2][(reg >> 8) & 0xffu] ^ T[1][(reg >> 16) & 0xffu] ^ T[0][reg >> 24];
+            }
+        }
+        // x^(8 * slice) mod P by square-and-multiply (wave-uniform), then the pairwise fold
+        uint32_t pw = 0x80000000u, sq = 0x40000000u;  // x^0, x^1
+#pragma nounroll
+        for (uint64_t e = 8u * slice; e != 0; e >>= 1) {
+            if (e & 1u) pw = gf2_mulmod(pw, sq);
+            sq = gf2_mulmod(sq, sq);
+        }
+#pragma nounroll
+        for (uint32_t d = 0; d < 6u; ++d) {
+            const uint32_t shifted = gf2_mulmod(reg, pw);
+            const uint32_t from_left = (uint32_t)__shfl_up((int)shifted, 1u << d, 64);
+            if ((lane & ((2u << d) - 1u)) == (2u << d) - 1u) reg ^= from_left;
+            pw = gf2_mulmod(pw, pw);
+        }
+        if (lane == 63u) {
+            const uint32_t ours = len ? ~reg : 0u, theirs = a.gz_expect[2 * (size_t)i], isize = a.gz_expect[2 * (size_t)i + 1];
+            if (a.adler) a.adler[i] = ours;
+            if (theirs != ours) {
+                a.status[i] = ST_CHECKSUM;
+                if (a.detail) {
+                    a.detail[2 * (size_t)i] = theirs;
+                    a.detail[2 * (size_t)i + 1] = ours;
+                }
+            } else if (isize != (uint32_t)len) {
+                a.status[i] = ST_GZIP_ISIZE;
+                if (a.detail) {
+                    a.detail[2 * (size_t)i] = isize;
+                    a.detail[2 * (size_t)i + 1] = (uint32_t)len;
+                }
+            }
+        }
     }
 }
 
@@ -94,18 +189,26 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     // Ring size classes.  15: the whole 32 KiB DEFLATE window is an LDS ring (4 stream-waves per CU).
     // 12-14: a smaller near ring plus far back-references served from the stream's own flushed output
     // (more resident stream-waves per CU; the kernel is latency-bound, so that is what it scales with).
+#define PZG_LAUNCH_RING(RB)                                                                   \
+    do {                                                                                      \
+        if (a.gzip)                                                                           \
+            hipLaunchKernelGGL((inflate_kernel<RB, false, true>), grid, block, 0, stream, a); \
+        else                                                                                  \
+            hipLaunchKernelGGL((inflate_kernel<RB, false, false>), grid, block, 0, stream, a); \
+    } while (0)
     if (ring_bits == 15)
-        hipLaunchKernelGGL((inflate_kernel<15, false>), grid, block, 0, stream, a);
+        PZG_LAUNCH_RING(15);
     else if (ring_bits == 14)
-        hipLaunchKernelGGL((inflate_kernel<14, false>), grid, block, 0, stream, a);
+        PZG_LAUNCH_RING(14);
     else if (ring_bits == 13)
-        hipLaunchKernelGGL((inflate_kernel<13, false>), grid, block, 0, stream, a);
+        PZG_LAUNCH_RING(13);
     else if (ring_bits == 12)
-        hipLaunchKernelGGL((inflate_kernel<12, false>), grid, block, 0, stream, a);
+        PZG_LAUNCH_RING(12);
     else if (ring_bits == 11)
-        hipLaunchKernelGGL((inflate_kernel<11, false>), grid, block, 0, stream, a);
+        PZG_LAUNCH_RING(11);
     else
         return hipErrorInvalidValue;
+#undef PZG_LAUNCH_RING
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ring_bits != 15) {
@@ -113,8 +216,16 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
         e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
         dim3 fgrid(a.n < 1024u ? a.n : 1024u);
-        hipLaunchKernelGGL((inflate_kernel<15, true>), fgrid, block, 0, stream, a);
+        if (a.gzip)
+            hipLaunchKernelGGL((inflate_kernel<15, true, true>), fgrid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((inflate_kernel<15, true, false>), fgrid, block, 0, stream, a);
     }
+    e = hipGetLastError();
+    if (e != hipSuccess || !a.gzip) return e;
+    // gzip members: CRC-32 and ISIZE of every decoded stream against its trailer (one more pass over the output)
+    dim3 cgrid(a.n < (uint32_t)num_cus * 16u ? a.n : (uint32_t)num_cus * 16u);
+    hipLaunchKernelGGL(crc32_verify_kernel, cgrid, block, 0, stream, a);
     return hipGetLastError();
 }
 

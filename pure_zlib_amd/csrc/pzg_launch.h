@@ -21,6 +21,8 @@ struct InflateArgs {
     uint32_t *counter;        // device word the persistent waves draw stream indices from (zeroed per launch)
     uint64_t *prof_out;       // diagnostic builds only (-DPZG_PROFILE): 12 counters per stream, else null
     uint32_t n;
+    uint32_t gzip;            // 0: zlib streams (RFC 1950, the reference's format); 1: gzip members (RFC 1952, an extension)
+    uint32_t *gz_expect;      // gzip only: 2n words of device scratch, the trailer's (CRC-32, ISIZE) of each stream
 };
 
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);

@@ -113,6 +113,8 @@ _STATUS_CONSTRUCTOR = {
     _ffi.E_BAD_LITLEN_SYMBOL: "ReferenceThrows",
     _ffi.E_BAD_DIST_SYMBOL: "ReferenceThrows",
     _ffi.E_DATA_REMAINING: "DecompressionError",
+    _ffi.E_GZIP_HEADER: "HeaderError",   # extension (PZG_GZIP): the reference has no gzip
+    _ffi.E_GZIP_ISIZE: "ChecksumError",
 }
 
 
@@ -176,7 +178,7 @@ class Context:
         return float(self._L.pzg_last_kernel_ms(self._h))
 
     # -- raw batched call on host memory ----------------------------------------------------------
-    def decompress_many_raw(self, in_buf: np.ndarray, in_off, in_len, out_buf: np.ndarray, out_off, out_cap):
+    def decompress_many_raw(self, in_buf: np.ndarray, in_off, in_len, out_buf: np.ndarray, out_off, out_cap, gzip: bool = False):
         """Thin wrapper of pzg_decompress_many on host numpy buffers.
         Returns (out_len u64[n], status i32[n], detail u32[n,2], in_used u64[n], adler u32[n])."""
         in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
@@ -194,15 +196,15 @@ class Context:
         rc = self._L.pzg_decompress_many(
             self._h, in_buf.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_buf.ctypes.data,
             out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data, status.ctypes.data, detail.ctypes.data,
-            in_used.ctypes.data, adler.ctypes.data, n, 0)
+            in_used.ctypes.data, adler.ctypes.data, n, _ffi.GZIP if gzip else 0)
         _ffi.check(rc, self._h)
         return out_len, status, detail, in_used, adler
 
     # -- device-pointer call (the timed path; pointers are raw integers) ----------------------------
     def decompress_many_device(self, in_base: int, in_off: int, in_len: int, out_base: int, out_off: int,
                                out_cap: int, out_len: int, status: int, detail: int, in_used: int, adler: int,
-                               n: int, sync: bool = True):
-        flags = _ffi.DEVICE_PTRS | (0 if sync else _ffi.ASYNC)
+                               n: int, sync: bool = True, gzip: bool = False):
+        flags = _ffi.DEVICE_PTRS | (0 if sync else _ffi.ASYNC) | (_ffi.GZIP if gzip else 0)
         rc = self._L.pzg_decompress_many(self._h, in_base, in_off, in_len, out_base, out_off, out_cap, out_len,
                                          status, detail or None, in_used or None, adler or None, n, flags)
         _ffi.check(rc, self._h)
@@ -246,7 +248,7 @@ def _align(x, a=256):
 
 
 def decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = None,
-                    size_hint: Optional[Sequence[int]] = None) -> List[Either]:
+                    size_hint: Optional[Sequence[int]] = None, gzip: bool = False) -> List[Either]:
     """decompressMany: every stream decoded by its own wavefront in one launch.
 
     zlib streams do not carry their decoded size, so each stream gets a capacity (size_hint[i] or a
@@ -276,7 +278,7 @@ def decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = 
         for k, i in enumerate(todo):
             in_buf[int(in_off[k]):int(in_off[k]) + len(flat[i])] = np.frombuffer(flat[i], dtype=np.uint8)
         out_buf = np.zeros(opos + 16, dtype=np.uint8)
-        out_len, status, detail, in_used, _adler = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap)
+        out_len, status, detail, in_used, _adler = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap, gzip)
         retry = []
         for k, i in enumerate(todo):
             st = int(status[k])
@@ -315,6 +317,13 @@ def decompress(ifile: LazyByteString, ctx: Optional[Context] = None, size_hint: 
 def adler32(data: bytes, init: int = 1, ctx: Optional[Context] = None) -> int:
     """Codec.Compression.Zlib.Adler32 over one buffer, as a device-wide reduction (Adler32.hs:17-57)."""
     return (ctx or default_context()).adler32(data, init)
+
+
+def gzip_decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = None,
+                         size_hint: Optional[Sequence[int]] = None) -> List[Either]:
+    """EXTENSION (the reference lists gzip as a TODO): decompress_many over RFC 1952
+    members -- same DEFLATE kernel, gzip header, CRC-32 + ISIZE trailer verified on the device."""
+    return decompress_many(streams, ctx, size_hint, gzip=True)
 
 
 # Haskell-cased aliases so call sites read like the reference

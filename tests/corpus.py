@@ -132,3 +132,25 @@ def fixed_blob(nbytes: int, seed: int) -> bytes:
 def level6_blob(nbytes: int, seed: int) -> bytes:
     """BASELINE config 4/5: zlib.compress(text, 6): one dynamic block at these sizes."""
     return zlib.compress(zipf_text(nbytes, seed), 6)
+
+
+def gzip_member(data: bytes, seed: int) -> bytes:
+    """One RFC 1952 member with seeded level and seeded optional header fields (FEXTRA, FNAME, FCOMMENT,
+    FHCRC), assembled by hand around a raw deflate body so every header form is exercised."""
+    import struct
+    rng = random.Random(seed)
+    co = zlib.compressobj(1 + seed % 9, zlib.DEFLATED, -15, rng.randint(1, 9),
+                          rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED]))
+    body = co.compress(data) + co.flush()
+    flg = rng.randrange(32) & 0x1e
+    hdr = bytearray(b"\x1f\x8b\x08" + bytes([flg]) + struct.pack("<I", seed * 977) + bytes([rng.choice([0, 2, 4]), rng.choice([0, 3, 255])]))
+    if flg & 4:
+        extra = bytes(rng.getrandbits(8) for _ in range(rng.randint(0, 40)))
+        hdr += struct.pack("<H", len(extra)) + extra
+    if flg & 8:
+        hdr += bytes(rng.randint(1, 255) for _ in range(rng.randint(0, 30))) + b"\x00"
+    if flg & 16:
+        hdr += bytes(rng.randint(1, 255) for _ in range(rng.randint(0, 300))) + b"\x00"
+    if flg & 2:
+        hdr += struct.pack("<H", zlib.crc32(bytes(hdr)) & 0xffff)
+    return bytes(hdr) + body + struct.pack("<II", zlib.crc32(data), len(data) & 0xffffffff)

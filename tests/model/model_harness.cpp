@@ -14,16 +14,28 @@ struct pzm_result {
     uint64_t out_len, in_used;
 };
 
-template <int RB>
+// what crc32_verify_kernel computes (bit by bit here; the kernel's slicing and GF(2) fold are GPU-tested)
+static uint32_t crc32_bits(const uint8_t *p, uint64_t n)
+{
+    uint32_t reg = 0xffffffffu;
+    for (uint64_t i = 0; i < n; ++i) {
+        reg ^= p[i];
+        for (int k = 0; k < 8; ++k) reg = (reg >> 1) ^ (0xedb88320u & (0u - (reg & 1u)));
+    }
+    return ~reg;
+}
+
+template <int RB, bool GZ = false>
 static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, pzm_result *r)
 {
+    const bool gzip = GZ;
     auto *lds = (pzg::WaveLds<RB> *)aligned_alloc(16, sizeof(pzg::WaveLds<RB>));
     memset(lds, 0xA5, sizeof(*lds));  // LDS is not zero-initialised on the device either
     // pad the input on both sides: the bit reader loads whole aligned dwords
     uint8_t *buf = (uint8_t *)malloc(in_len + 16);
     memset(buf, 0xEE, in_len + 16);
     if (in_len) memcpy(buf + 8, in, in_len);
-    pzg::Decoder<RB> dec(*lds);
+    pzg::Decoder<RB, GZ> dec(*lds);
     pzg::StreamResult sr;
     dec.run(buf + 8, in_len, out, cap, &sr);
     r->status = sr.status;
@@ -32,6 +44,20 @@ static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t c
     r->adler = sr.adler;
     r->out_len = sr.out_len;
     r->in_used = sr.in_used;
+    if (gzip && sr.status == pzg::ST_OK) {  // the verify pass of the gzip launch
+        const uint32_t ours = crc32_bits(out, sr.out_len);
+        r->adler = ours;
+        r->detail0 = r->detail1 = 0;  // on success they carried the trailer's CRC-32 and ISIZE
+        if (sr.detail0 != ours) {
+            r->status = pzg::ST_CHECKSUM;
+            r->detail0 = sr.detail0;
+            r->detail1 = ours;
+        } else if (sr.detail1 != (uint32_t)sr.out_len) {
+            r->status = pzg::ST_GZIP_ISIZE;
+            r->detail0 = sr.detail1;
+            r->detail1 = (uint32_t)sr.out_len;
+        }
+    }
     free(buf);
     free(lds);
 }
@@ -47,6 +73,17 @@ int pzm_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t ca
     else if (ring_bits == 11) run_one<11>(in, in_len, out, cap, r);
     else return -1;
     if (r->status == pzg::ST_RETRY_FULL_RING) run_one<15>(in, in_len, out, cap, r);  // what the fixup launch does
+    return 0;
+}
+
+int pzm_decompress_gzip(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, int ring_bits, pzm_result *r)
+{
+    if (ring_bits == 15) run_one<15, true>(in, in_len, out, cap, r);
+    else if (ring_bits == 13) run_one<13, true>(in, in_len, out, cap, r);
+    else if (ring_bits == 12) run_one<12, true>(in, in_len, out, cap, r);
+    else if (ring_bits == 11) run_one<11, true>(in, in_len, out, cap, r);
+    else return -1;
+    if (r->status == pzg::ST_RETRY_FULL_RING) run_one<15, true>(in, in_len, out, cap, r);
     return 0;
 }
 

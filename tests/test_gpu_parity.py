@@ -24,7 +24,7 @@ def ctx(gpu_ctx, request):
     gpu_ctx.set_ring_bits(11)
 
 
-def run_batch(ctx, streams, caps, align=16):
+def run_batch(ctx, streams, caps, align=16, gzip=False):
     """Lay the streams out in arenas (each extent `align`-aligned) and call pzg_decompress_many."""
     n = len(streams)
     in_off = np.zeros(n, dtype=np.uint64)
@@ -40,7 +40,7 @@ def run_batch(ctx, streams, caps, align=16):
     out_buf = np.full(op + 16, 0xCD, dtype=np.uint8)
     in_len = np.array([len(s) for s in streams], dtype=np.uint64)
     out_cap = np.array(caps, dtype=np.uint64)
-    res = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap)
+    res = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap, gzip=gzip)
     outs = [out_buf[int(out_off[k]):int(out_off[k]) + min(int(res[0][k]), caps[k])].tobytes() for k in range(n)]
     return res, outs, out_buf, out_off
 
@@ -318,3 +318,40 @@ def test_cxx_module_mirror_reads_like_the_reference_tests():
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "ref")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(" OK") == 18 and "0 failure(s)" in out.stdout
+
+
+def test_gzip_members_extension(ctx, oracle):
+    """SURVEY 8f row 4 (an extension: the reference has no gzip): RFC 1952 members through PZG_GZIP -- same DEFLATE
+    kernel, gzip header forms, CRC-32 (slicing + GF(2) fold kernel) and ISIZE verified on the device -- against
+    system zlib (wbits 31) for valid members of many sizes and the oracle for corrupted ones."""
+    import pure_zlib_amd as P
+    streams, datas = [], []
+    sizes = [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1000, 4093, 4096, 33000, 70001, 262144 + 3, 1 << 20]
+    for seed in range(300):
+        n = sizes[seed % len(sizes)] if seed % 3 == 0 else (seed * 131) % 20000
+        d = corpus.mixed_data(n, seed) if seed % 2 else corpus.html_slice(min(n, 100000), seed)
+        streams.append(corpus.gzip_member(d, seed))
+        datas.append(d)
+    (out_len, status, detail, in_used, crc), outs, _, _ = run_batch(ctx, streams, [len(d) for d in datas], gzip=True)
+    for k in range(len(streams)):
+        assert zlib.decompress(streams[k], 31) == datas[k]
+        assert status[k] == 0 and outs[k] == datas[k], (k, len(datas[k]), status[k], detail[k])
+        assert int(crc[k]) == zlib.crc32(datas[k]) and int(in_used[k]) == len(streams[k]) and int(out_len[k]) == len(datas[k])
+    bad = [corpus.corrupt(streams[k % 300], 5000 + k) for k in range(1200)]
+    caps = [len(datas[k % 300]) + 4096 for k in range(1200)]
+    (out_len, status, detail, in_used, crc), outs, _, _ = run_batch(ctx, bad, caps, gzip=True)
+    for k in range(len(bad)):
+        r, o = oracle.gzip_decompress(bad[k], caps[k])
+        if int(status[k]) == 14 and r.status in (10, 19):
+            assert int(out_len[k]) == r.out_len  # documented: CRC/ISIZE of an unstored output are not verified
+            continue
+        assert int(status[k]) == r.status, (k, status[k], r.status, r.message)
+        if r.status == 0:
+            assert outs[k] == o and int(crc[k]) == r.adler
+        elif r.status in (10, 19):
+            assert [int(detail[k][0]), int(detail[k][1])] == [r.detail0, r.detail1]
+    # the mirror API
+    rs = P.gzip_decompress_many(streams[:20], ctx=ctx)
+    assert rs == [P.Right(d) for d in datas[:20]]
+    e = P.gzip_decompress_many([b"\x1f\x8c" + streams[1][2:]], ctx=ctx)[0]
+    assert isinstance(e, P.Left) and e.value.show() == "Header error: gzip: bad magic"

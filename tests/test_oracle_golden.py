@@ -123,3 +123,31 @@ def test_pinned_generated_vectors(oracle, v):
                 zlib.decompress(z[: r.in_used])
         else:
             assert zlib.decompress(z[: r.in_used]) == out
+
+
+def test_oracle_gzip_extension_against_system_zlib(oracle):
+    """RFC 1952 members (an extension: the reference has no gzip, so this part of the oracle is pinned against
+    system zlib, wbits = 31, not against pure-zlib): valid members with every optional header field, then
+    single-bit corruptions where the oracle and zlib must agree on accept / reject."""
+    import corpus
+    assert oracle.crc32(b"123456789") == 0xCBF43926
+    for seed in range(120):
+        d = corpus.mixed_data((seed * 977) % 40000, seed)
+        z = corpus.gzip_member(d, seed)
+        assert zlib.decompress(z, 31) == d
+        r, o = oracle.gzip_decompress(z, len(d) + 8)
+        assert r.status == 0 and o == d and r.adler == zlib.crc32(d) and r.in_used == len(z), (seed, r.status, r.message)
+        for c in range(4):
+            zz = bytearray(z)
+            pos = (seed * 7919 + c * 104729) % len(zz)
+            zz[pos] ^= 1 << ((seed + c) % 8)
+            r2, o2 = oracle.gzip_decompress(bytes(zz), len(d) + 8)
+            try:
+                ref = zlib.decompress(bytes(zz), 31)
+            except zlib.error:
+                ref = None
+            if ref is None:
+                # (MTIME/XFL/OS/FNAME bytes are not covered by anything unless FHCRC is set: both accept those)
+                assert r2.status != 0, (seed, c, pos)
+            else:
+                assert r2.status == 0 and o2 == ref, (seed, c, pos, r2.status)
