@@ -1300,7 +1300,7 @@ struct Decoder {
     static constexpr uint32_t FIXED_MAGIC = 0x51DF1BEDu;
     PZG_FN void load_fixed_tables()
     {
-        lit_n = 288u;  // (no fixed code is longer than its primary table, so lens is never consulted for it)
+        lit_n = 288u;
         dist_n = 32u;
         if (uni(L.fixed_ready) == FIXED_MAGIC) {  // still there from an earlier block or stream of this wave
             lit_e15 = dist_e15 = 32768u;
@@ -1315,6 +1315,10 @@ struct Decoder {
         build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, &L.lit_meta, &lit_e15);
         build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, &L.dist_meta, &dist_e15);
         if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = FIXED_MAGIC;
+        // Not a Huffman-optimal code: how often its 9-bit literals (144..255) occur is up to the data, and in text
+        // they do not.  The windows skip the second-level lookup for fixed blocks (as on the cached path above);
+        // a long literal ends the walk and the checked path resolves it through the same tables.
+        use_sub = 0u;
         wave_sync();
     }
 
