@@ -355,3 +355,18 @@ def test_gzip_members_extension(ctx, oracle):
     assert rs == [P.Right(d) for d in datas[:20]]
     e = P.gzip_decompress_many([b"\x1f\x8c" + streams[1][2:]], ctx=ctx)[0]
     assert isinstance(e, P.Left) and e.value.show() == "Header error: gzip: bad magic"
+
+
+def test_large_stream_and_many_tiny_streams(ctx):
+    """Scale edges: one 48 MiB multi-block stream on a single wavefront (64-bit cursors, thousands of flushes,
+    far reads across the whole run) and 200,000 tiny streams in one launch (the persistent waves' queue)."""
+    big = corpus.html_slice(100000, 3) * 300 + corpus.skewed_bytes(1 << 20, 5) + corpus.zipf_text(16 << 20, 9)
+    co = zlib.compressobj(6)
+    zbig = b"".join(co.compress(big[i:i + (1 << 20)]) + co.flush(zlib.Z_FULL_FLUSH if i % 3 == 0 else zlib.Z_SYNC_FLUSH)
+                    for i in range(0, len(big), 1 << 20)) + co.flush()
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, [zbig], [len(big)])
+    assert status[0] == 0 and int(out_len[0]) == len(big) and int(adler[0]) == zlib.adler32(big) and outs[0] == big
+    tiny_d = [bytes([k % 251]) * (k % 40) + str(k).encode() for k in range(200000)]
+    tiny_z = [zlib.compress(d, 1 + k % 9) for k, d in enumerate(tiny_d)]
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, tiny_z, [len(d) for d in tiny_d])
+    assert (status == 0).all() and all(o == d for o, d in zip(outs, tiny_d))
