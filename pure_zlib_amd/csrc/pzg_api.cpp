@@ -8,7 +8,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -243,7 +246,14 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     uint8_t *d_out = (uint8_t *)ctx->a_out.p + out_skew;
     uint8_t *d_meta = (uint8_t *)ctx->a_meta.p;
     hipStream_t s = ctx->stream;
+    const bool trace = getenv("PZG_TRACE_HOST") != nullptr;
+    const auto t_h2d0 = std::chrono::steady_clock::now();
     if (in_bytes) HIP_TRY(ctx, hipMemcpyAsync(d_in, in_base + in_lo, in_bytes, hipMemcpyHostToDevice, s));
+    if (trace) {
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[pzg] host path: H2D of %.1f MiB: %.1f ms\n", in_bytes / 1048576.0,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count());
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_off, in_off, 8 * N, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_len, in_len, 8 * N, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_off, out_off, 8 * N, hipMemcpyHostToDevice, s));
@@ -293,11 +303,37 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
             }
             ctx->h_stage_cap = out_bytes;
         }
+        const auto t_d2h0 = std::chrono::steady_clock::now();
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage, d_out, out_bytes, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint64_t nb = out_len[i] < out_cap[i] ? out_len[i] : out_cap[i];
-            if (nb) memcpy(out_base + out_off[i], (const uint8_t *)ctx->h_stage + (out_off[i] - out_lo), nb);
+        if (trace)
+            fprintf(stderr, "[pzg] host path: D2H of %.1f MiB into pinned staging: %.1f ms\n", out_bytes / 1048576.0,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count());
+        const auto t_copy0 = std::chrono::steady_clock::now();
+        const uint8_t *stage = (const uint8_t *)ctx->h_stage;
+        auto copy_range = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint64_t nb = out_len[i] < out_cap[i] ? out_len[i] : out_cap[i];
+                if (nb) memcpy(out_base + out_off[i], stage + (out_off[i] - out_lo), nb);
+            }
+        };
+        // big batches: the per-stream copies out of the staging buffer are memory-bound host work, split over a few threads
+        uint32_t nthreads = 1;
+        if (out_bytes >= (64u << 20) && n >= 64u) {
+            nthreads = std::thread::hardware_concurrency();
+            nthreads = nthreads > 8u ? 8u : nthreads < 1u ? 1u : nthreads;
+        }
+        if (nthreads == 1) {
+            copy_range(0, n);
+        } else {
+            std::vector<std::thread> pool;
+            for (uint32_t t = 0; t < nthreads; ++t)
+                pool.emplace_back(copy_range, (uint32_t)((uint64_t)n * t / nthreads), (uint32_t)((uint64_t)n * (t + 1) / nthreads));
+            for (auto &th : pool) th.join();
+        }
+        if (trace) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copy0).count();
+            fprintf(stderr, "[pzg] host path: copy-out of %.1f MiB on %u thread(s): %.1f ms\n", out_bytes / 1048576.0, nthreads, ms);
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
