@@ -778,7 +778,10 @@ struct Decoder {
     // A queued token is one dword:  literal  LIT_FLAG | 1 << 16 | byte      match  len << 16 | dist.
     static constexpr uint32_t LIT_FLAG = 0x80000000u;
     static constexpr uint32_t QCAP = 63u;   // queue lanes 0..62; lane 63 receives what the compaction discards
-    static constexpr uint32_t QHIGH = 40u;  // emit when this many tokens wait (room for any ordinary window stays)
+#ifndef PZG_QHIGH
+#define PZG_QHIGH 40
+#endif
+    static constexpr uint32_t QHIGH = PZG_QHIGH;  // emit when this many tokens wait (room for any ordinary window stays)
 
     PZG_FN void queue_push(uint32_t tk)  // qn < QCAP
     {
