@@ -115,7 +115,8 @@ int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
  *   adler[n]               Adler-32 computed over the decoded bytes; may be NULL
  *
  * Extents may be laid out with gaps (aligned arenas) and in any order; they must not overlap on the
- * output side.  A 16-byte aligned out_base+out_off[i] takes the wide (16 B/lane) store path.
+ * output side.  One compressed stream may be up to 16 GiB (longer ones report PZG_E_TRUNCATED); the decoded size is
+ * not limited.  A 16-byte aligned out_base+out_off[i] takes the wide (16 B/lane) store path.
  *
  * Without PZG_DEVICE_PTRS all pointers are host memory and the call stages through the
  * context's device arenas (H2D, kernel, D2H) and returns when results are in host memory.

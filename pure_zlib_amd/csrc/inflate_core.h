@@ -1431,7 +1431,8 @@ struct Decoder {
         in_byte0 = 0;
         br.start(in, in_len, 0);
         PZG_T0(tall);
-        decode();
+        if (in_len >> 34) fail(ST_TRUNCATED, 0, 0);  // the reader indexes dwords with 32 bits: 16 GiB per stream (include/pzg.h)
+        else decode();
         PZG_ACC(0, tall);
         uint64_t used_bits = stream_bit_pos();
         uint64_t used = (used_bits + 7u) >> 3;
