@@ -986,9 +986,9 @@ struct Decoder {
             kend += lane_get(TB, kend);
         } while (kend < 64u);
         // the chain's last token is the only one that can be a stopper (it ends the walk)
-        LaneVec<uint32_t> ST;
+        LaneVec<bool> ST;
         PZG_LANES_BEGIN(k)
-            PZG_LV(ST, k) = PZG_LV(TB, k) == 64u ? 1u : 0u;
+            PZG_LV(ST, k) = PZG_LV(TB, k) == 64u;
         PZG_LANES_END
         const uint64_t stopbit = S & lanes_ballot(ST);
         bool stopper = stopbit != 0;
@@ -998,9 +998,9 @@ struct Decoder {
         const uint32_t room = QCAP - qn;
         uint32_t nt = popc64(tokens);
         if (nt > room) {  // (a window of very short codes) take what fits, the rest is decoded again
-            LaneVec<uint32_t> FIRST_OUT;
+            LaneVec<bool> FIRST_OUT;
             PZG_LANES_BEGIN(k)
-                PZG_LV(FIRST_OUT, k) = (((tokens >> k) & 1ull) && mbcnt_k(tokens, k) == room) ? 1u : 0u;
+                PZG_LV(FIRST_OUT, k) = lane_bit(tokens, k) && mbcnt_k(tokens, k) == room;
             PZG_LANES_END
             consumed = ctz64(lanes_ballot(FIRST_OUT));
             tokens &= (1ull << consumed) - 1ull;
@@ -1012,7 +1012,7 @@ struct Decoder {
 #endif
         LaneVec<uint32_t> DEST, RECV;
         PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = ((tokens >> k) & 1ull) ? qn + mbcnt_k(tokens, k) : 63u;
+            PZG_LV(DEST, k) = lane_bit(tokens, k) ? qn + mbcnt_k(tokens, k) : 63u;
         PZG_LANES_END
         lanes_scatter(RECV, TK, DEST);
         PZG_LANES_BEGIN(j)
@@ -1054,7 +1054,7 @@ struct Decoder {
         prof[6] += 2;
 #endif
         // ---- the walk: first half, and unless it ended at a stopper, the second -------------------------
-        LaneVec<uint32_t> ST;
+        LaneVec<bool> ST;
         uint64_t S0 = 0, S1 = 0;
         uint32_t kend = 0;
         do {
@@ -1066,7 +1066,7 @@ struct Decoder {
             kend += lane_get(TB0, kend);
         } while (kend < 64u);
         PZG_LANES_BEGIN(k)
-            PZG_LV(ST, k) = PZG_LV(TB0, k) == 64u ? 1u : 0u;
+            PZG_LV(ST, k) = PZG_LV(TB0, k) == 64u;
         PZG_LANES_END
         const uint64_t stop0 = S0 & lanes_ballot(ST);
         const uint32_t kend0 = stop0 ? kend - 64u : kend;  // where the first half's chain stops (a stopper) or leaves it
@@ -1082,7 +1082,7 @@ struct Decoder {
                 kend += lane_get(TB1, kend);
             }
             PZG_LANES_BEGIN(k)
-                PZG_LV(ST, k) = PZG_LV(TB1, k) == 64u ? 1u : 0u;
+                PZG_LV(ST, k) = PZG_LV(TB1, k) == 64u;
             PZG_LANES_END
             stop1 = S1 & lanes_ballot(ST);
             kend = stop1 ? kend : kend + 64u;  // back to an offset from the cursor (a stopper at k1: k1 + 64 already)
@@ -1100,9 +1100,9 @@ struct Decoder {
             consumed = kend0;
             stopper = stop0 != 0;
             if (nt0 > room) {
-                LaneVec<uint32_t> FIRST_OUT;
+                LaneVec<bool> FIRST_OUT;
                 PZG_LANES_BEGIN(k)
-                    PZG_LV(FIRST_OUT, k) = (((tokens0 >> k) & 1ull) && mbcnt_k(tokens0, k) == room) ? 1u : 0u;
+                    PZG_LV(FIRST_OUT, k) = lane_bit(tokens0, k) && mbcnt_k(tokens0, k) == room;
                 PZG_LANES_END
                 consumed = ctz64(lanes_ballot(FIRST_OUT));
                 tokens0 &= (1ull << consumed) - 1ull;
@@ -1115,11 +1115,11 @@ struct Decoder {
 #endif
         LaneVec<uint32_t> DEST, R0, R1;
         PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = ((tokens0 >> k) & 1ull) ? qn + mbcnt_k(tokens0, k) : 63u;
+            PZG_LV(DEST, k) = lane_bit(tokens0, k) ? qn + mbcnt_k(tokens0, k) : 63u;
         PZG_LANES_END
         lanes_scatter(R0, TK0, DEST);
         PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = ((tokens1 >> k) & 1ull) ? qn + nt0 + mbcnt_k(tokens1, k) : 63u;
+            PZG_LV(DEST, k) = lane_bit(tokens1, k) ? qn + nt0 + mbcnt_k(tokens1, k) : 63u;
         PZG_LANES_END
         lanes_scatter(R1, TK1, DEST);
         PZG_LANES_BEGIN(j)
@@ -1145,9 +1145,10 @@ struct Decoder {
         complete_pending();  // the previous segment's bytes must be in the ring (and in `op`) from here on
         PZG_ACCW(8, t_a);
         PZG_T0(t_b);
-        const uint32_t hist = op > 0x100000u ? 0x100000u : (uint32_t)op;  // dist <= 32768: a clamp is enough
+        const uint32_t hist = (op >> 20) ? 0x100000u : (uint32_t)op;  // dist <= 32768: a clamp is enough (scalar shift + test)
         const uint32_t op32 = (uint32_t)op;
-        LaneVec<uint32_t> INCL, STOP;
+        LaneVec<uint32_t> INCL;
+        LaneVec<bool> STOP;
         PZG_LANES_BEGIN(t)
             PZG_LV(INCL, t) = t < qn ? ((PZG_LV(QT, t) >> 16) & 511u) : 0u;
         PZG_LANES_END
@@ -1156,7 +1157,8 @@ struct Decoder {
             const uint32_t tk = PZG_LV(QT, t), lout = (tk >> 16) & 511u, dist = tk & 0xffffu;
             const uint32_t endb = PZG_LV(INCL, t), start = endb - lout;
             const bool is_match = (tk & LIT_FLAG) == 0u;
-            PZG_LV(STOP, t) = (t < qn && (endb > 64u || (is_match && (dist < endb || dist > hist + start)))) ? 1u : 0u;
+            // (bitwise, not short-circuit: one straight-line predicate instead of a lane-dependent branch)
+            PZG_LV(STOP, t) = (t < qn) & ((endb > 64u) | (is_match & ((dist < endb) | (dist > hist + start))));
         PZG_LANES_END
         const uint64_t stopmask = lanes_ballot(STOP);
         uint32_t v = stopmask ? ctz64(stopmask) : qn;  // tokens of this segment
@@ -1189,7 +1191,7 @@ struct Decoder {
             lanes_scatter(MARK, ONE, DEST);
             const uint64_t starts = lanes_ballot(MARK);
             PZG_LANES_BEGIN(j)
-                PZG_LV(TOK, j) = (mbcnt_k(starts, j) + (uint32_t)((starts >> j) & 1ull) - 1u) & 63u;
+                PZG_LV(TOK, j) = (mbcnt_k(starts, j) - (lane_bit(starts, j) ? 0u : 1u)) & 63u;
             PZG_LANES_END
             lanes_gather(PJ, QT, TOK);
             LaneVec<uint32_t> BV;
@@ -1202,16 +1204,16 @@ struct Decoder {
             PZG_ACCW(10, t_c);
             PZG_T0(t_d);
             if (HYBRID) {  // sources older than the ring: the stream's own flushed output
-                LaneVec<uint32_t> FAR;
+                LaneVec<bool> FAR;
                 PZG_LANES_BEGIN(j)
                     const uint32_t pj = PZG_LV(PJ, j);
-                    PZG_LV(FAR, j) = (j < run && (pj & LIT_FLAG) == 0u && (pj & 0xffffu) - j > RING) ? 1u : 0u;
+                    PZG_LV(FAR, j) = (j < run) & ((pj & LIT_FLAG) == 0u) & ((pj & 0xffffu) - j > RING);
                 PZG_LANES_END
                 if (lanes_ballot(FAR)) {
                     far_fence();
                     pend_far = 1u;
                     PZG_LANES_BEGIN(j)
-                        const bool far = PZG_LV(FAR, j) != 0u;
+                        const bool far = PZG_LV(FAR, j);
                         PZG_LV(pendFV, j) = fetch_far(far, (PZG_LV(PJ, j) & 0xffffu) - j);  // issued now, waited for in complete_pending()
                         PZG_LV(BV, j) = (PZG_LV(BV, j) & 0xffu) | (far ? 0x100u : 0u);
                     PZG_LANES_END

@@ -181,6 +181,18 @@ PZG_FN uint32_t lane_get(const LaneVec<uint32_t> &x, uint32_t l)
 #endif
 }
 
+// bit k of a wave-uniform mask, as lane k's predicate: on the device the mask itself is the select/branch condition
+// (inverse ballot), no shift and no compare
+PZG_FN bool lane_bit(uint64_t m, uint32_t k)
+{
+#if PZG_DEVICE_PASS
+    (void)k;
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+#else
+    return ((m >> k) & 1ull) != 0;
+#endif
+}
+
 // number of set bits of m below lane k
 PZG_FN uint32_t mbcnt_k(uint64_t m, uint32_t k)
 {
@@ -276,6 +288,18 @@ PZG_FN uint64_t lanes_ballot(const LaneVec<uint32_t> &p)
 #else
     uint64_t m = 0;
     for (uint32_t k = 0; k < 64u; ++k) m |= (uint64_t)(p.v[k] != 0u) << k;
+    return m;
+#endif
+}
+
+// the same for a LaneVec of predicates (no 0/1 integers in between)
+PZG_FN uint64_t lanes_ballot(const LaneVec<bool> &p)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_ballot_w64(p.v);
+#else
+    uint64_t m = 0;
+    for (uint32_t k = 0; k < 64u; ++k) m |= (uint64_t)p.v[k] << k;
     return m;
 #endif
 }
