@@ -42,6 +42,8 @@ struct pzg_ctx {
     std::string last_error;
     void *prof_buf = nullptr;  // diagnostic builds only
     void *d_counter = nullptr; // stream-index counter of the persistent inflate waves
+    hipStream_t s_up = nullptr, s_dn = nullptr;  // host-pointer path of big batches: H2D and D2H beside the kernel stream
+    hipEvent_t ev_up[8] = {}, ev_k[8] = {}, ev_dn[8] = {};
     int ring_bits = PZG_DEFAULT_RING_BITS;
     int num_cus = 256;
 };
@@ -76,6 +78,20 @@ int arena_reserve(pzg_ctx *ctx, Arena &a, size_t bytes)
         return PZG_RC_NO_MEMORY;
     }
     a.cap = bytes;
+    return PZG_RC_OK;
+}
+
+// the two copy streams and the per-range events of the pipelined host-pointer path, created on first use
+int ensure_pipeline(pzg_ctx *ctx)
+{
+    if (ctx->s_up) return PZG_RC_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_dn, hipStreamNonBlocking));
+    for (int c = 0; c < 8; ++c) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_up[c], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_k[c], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_dn[c], hipEventDisableTiming));
+    }
     return PZG_RC_OK;
 }
 
@@ -149,6 +165,13 @@ void pzg_shutdown(pzg_ctx *ctx)
     if (ctx->d_counter) (void)hipFree(ctx->d_counter);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int c = 0; c < 8; ++c) {
+        if (ctx->ev_up[c]) (void)hipEventDestroy(ctx->ev_up[c]);
+        if (ctx->ev_k[c]) (void)hipEventDestroy(ctx->ev_k[c]);
+        if (ctx->ev_dn[c]) (void)hipEventDestroy(ctx->ev_dn[c]);
+    }
+    if (ctx->s_up) (void)hipStreamDestroy(ctx->s_up);
+    if (ctx->s_dn) (void)hipStreamDestroy(ctx->s_dn);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -220,7 +243,9 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
         return PZG_RC_OK;
     }
 
-    // host-pointer path: stage the covering byte ranges through the context's arenas
+    // host-pointer path: stage the covering byte ranges through the context's arenas.  A big batch is cut into
+    // index ranges that flow through three HIP streams -- H2D of range c+1, the kernel on range c, D2H of range
+    // c-1 into pinned staging -- while host threads copy range c-2 out to the caller's extents.
     uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (in_off[i] < in_lo) in_lo = in_off[i];
@@ -242,101 +267,150 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     const size_t m_in_off = 0, m_in_len = 8 * N, m_out_off = 16 * N, m_out_cap = 24 * N, m_out_len = 32 * N,
                  m_in_used = 40 * N, m_status = 48 * N, m_adler = 52 * N, m_detail = 56 * N, m_total = 64 * N;
     if ((rc = arena_reserve(ctx, ctx->a_meta, m_total)) != PZG_RC_OK) return rc;
+    if ((flags & PZG_GZIP) && (rc = arena_reserve(ctx, ctx->a_gz, 8 * N)) != PZG_RC_OK) return rc;
+    if (out_bytes && ctx->h_stage_cap < out_bytes) {
+        if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
+        ctx->h_stage = nullptr;
+        ctx->h_stage_cap = 0;
+        hipError_t e = hipHostMalloc(&ctx->h_stage, out_bytes + 64, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            hip_fail(ctx, e, "hipHostMalloc");
+            return PZG_RC_NO_MEMORY;
+        }
+        ctx->h_stage_cap = out_bytes;
+    }
     uint8_t *d_in = (uint8_t *)ctx->a_in.p + in_skew;
     uint8_t *d_out = (uint8_t *)ctx->a_out.p + out_skew;
     uint8_t *d_meta = (uint8_t *)ctx->a_meta.p;
-    hipStream_t s = ctx->stream;
+    uint8_t *stage = (uint8_t *)ctx->h_stage;
     const bool trace = getenv("PZG_TRACE_HOST") != nullptr;
-    const auto t_h2d0 = std::chrono::steady_clock::now();
-    if (in_bytes) HIP_TRY(ctx, hipMemcpyAsync(d_in, in_base + in_lo, in_bytes, hipMemcpyHostToDevice, s));
-    if (trace) {
-        (void)hipStreamSynchronize(s);
-        fprintf(stderr, "[pzg] host path: H2D of %.1f MiB: %.1f ms\n", in_bytes / 1048576.0,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h2d0).count());
+    const auto t_call0 = std::chrono::steady_clock::now();
+
+    // index ranges: one for a small batch, four when there is enough to overlap (more only adds kernel tails:
+    // measured 91 / 83 / 79 / 77 / 78 ms for 1 / 2 / 3 / 4 / 8 ranges on the 65,536 x 32 KiB batch)
+    uint32_t nchunk = 1;
+    if (n >= 4096u && in_bytes + out_bytes >= (256ull << 20)) nchunk = 4u;
+    if (const char *e = getenv("PZG_HOST_RANGES")) {  // experiment knob
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8 && (uint32_t)v <= n) nchunk = (uint32_t)v;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_off, in_off, 8 * N, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_len, in_len, 8 * N, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_off, out_off, 8 * N, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_cap, out_cap, 8 * N, hipMemcpyHostToDevice, s));
-    pzg::InflateArgs a{};
-    a.in_base = d_in - in_lo;  // offsets stay the caller's
-    a.out_base = d_out - out_lo;
-    a.in_off = (const uint64_t *)(d_meta + m_in_off);
-    a.in_len = (const uint64_t *)(d_meta + m_in_len);
-    a.out_off = (const uint64_t *)(d_meta + m_out_off);
-    a.out_cap = (const uint64_t *)(d_meta + m_out_cap);
-    a.out_len = (uint64_t *)(d_meta + m_out_len);
-    a.in_used = (uint64_t *)(d_meta + m_in_used);
-    a.status = (int32_t *)(d_meta + m_status);
-    a.adler = (uint32_t *)(d_meta + m_adler);
-    a.detail = (uint32_t *)(d_meta + m_detail);
-    a.order = nullptr;
-    a.prof_out = nullptr;
-#if defined(PZG_PROFILE)
-    a.prof_out = (uint64_t *)ctx->prof_buf;
-#endif
-    a.n = n;
-    if (flags & PZG_GZIP) {
-        if ((rc = arena_reserve(ctx, ctx->a_gz, 8 * (size_t)n)) != PZG_RC_OK) return rc;
-        a.gzip = 1;
-        a.gz_expect = (uint32_t *)ctx->a_gz.p;
+    if (nchunk > 1 && ensure_pipeline(ctx) != PZG_RC_OK) nchunk = 1;
+    hipStream_t s_k = ctx->stream;                               // kernels: the context's (or the caller's) stream
+    hipStream_t s_up = nchunk > 1 ? ctx->s_up : ctx->stream;     // H2D
+    hipStream_t s_dn = nchunk > 1 ? ctx->s_dn : ctx->stream;     // D2H
+    uint32_t cthreads = 1;
+    if (out_bytes >= (64ull << 20) && n >= 64u) {
+        cthreads = std::thread::hardware_concurrency();
+        cthreads = cthreads > 8u ? 8u : cthreads < 1u ? 1u : cthreads;
     }
-    if ((rc = launch_timed(ctx, a)) != PZG_RC_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out_len, a.out_len, 8 * N, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(status, a.status, 4 * N, hipMemcpyDeviceToHost, s));
-    if (in_used) HIP_TRY(ctx, hipMemcpyAsync(in_used, a.in_used, 8 * N, hipMemcpyDeviceToHost, s));
-    if (adler) HIP_TRY(ctx, hipMemcpyAsync(adler, a.adler, 4 * N, hipMemcpyDeviceToHost, s));
-    if (detail) HIP_TRY(ctx, hipMemcpyAsync(detail, a.detail, 8 * N, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    // copy back only what each stream produced (capacities may be far larger than the outputs)
-    // One D2H transfer of the covering range into pinned staging, then per-stream copies into the
-    // caller's extents: bytes outside [out_off, out_off + min(out_len, out_cap)) are never touched.
-    if (out_bytes) {
-        if (ctx->h_stage_cap < out_bytes) {
-            if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
-            ctx->h_stage = nullptr;
-            ctx->h_stage_cap = 0;
-            hipError_t e = hipHostMalloc(&ctx->h_stage, out_bytes + 64, hipHostMallocDefault);
-            if (e != hipSuccess) {
-                hip_fail(ctx, e, "hipHostMalloc");
-                return PZG_RC_NO_MEMORY;
-            }
-            ctx->h_stage_cap = out_bytes;
-        }
-        const auto t_d2h0 = std::chrono::steady_clock::now();
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage, d_out, out_bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (trace)
-            fprintf(stderr, "[pzg] host path: D2H of %.1f MiB into pinned staging: %.1f ms\n", out_bytes / 1048576.0,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_d2h0).count());
-        const auto t_copy0 = std::chrono::steady_clock::now();
-        const uint8_t *stage = (const uint8_t *)ctx->h_stage;
-        auto copy_range = [&](uint32_t lo, uint32_t hi) {
-            for (uint32_t i = lo; i < hi; ++i) {
+    auto copy_out = [&](uint32_t lo, uint32_t hi) {  // per-stream copies out of staging: only [out_off, out_off + min(out_len, out_cap))
+        auto part = [&](uint32_t a0, uint32_t a1) {
+            for (uint32_t i = a0; i < a1; ++i) {
                 const uint64_t nb = out_len[i] < out_cap[i] ? out_len[i] : out_cap[i];
                 if (nb) memcpy(out_base + out_off[i], stage + (out_off[i] - out_lo), nb);
             }
         };
-        // big batches: the per-stream copies out of the staging buffer are memory-bound host work, split over a few threads
-        uint32_t nthreads = 1;
-        if (out_bytes >= (64u << 20) && n >= 64u) {
-            nthreads = std::thread::hardware_concurrency();
-            nthreads = nthreads > 8u ? 8u : nthreads < 1u ? 1u : nthreads;
+        const uint32_t m = hi - lo;
+        if (cthreads == 1 || m < 64u) {
+            part(lo, hi);
+            return;
         }
-        if (nthreads == 1) {
-            copy_range(0, n);
-        } else {
-            std::vector<std::thread> pool;
-            for (uint32_t t = 0; t < nthreads; ++t)
-                pool.emplace_back(copy_range, (uint32_t)((uint64_t)n * t / nthreads), (uint32_t)((uint64_t)n * (t + 1) / nthreads));
-            for (auto &th : pool) th.join();
-        }
-        if (trace) {
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copy0).count();
-            fprintf(stderr, "[pzg] host path: copy-out of %.1f MiB on %u thread(s): %.1f ms\n", out_bytes / 1048576.0, nthreads, ms);
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < cthreads; ++t)
+            pool.emplace_back(part, lo + (uint32_t)((uint64_t)m * t / cthreads), lo + (uint32_t)((uint64_t)m * (t + 1) / cthreads));
+        for (auto &th : pool) th.join();
+    };
+
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_off, in_off, 8 * N, hipMemcpyHostToDevice, s_up));
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_len, in_len, 8 * N, hipMemcpyHostToDevice, s_up));
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_off, out_off, 8 * N, hipMemcpyHostToDevice, s_up));
+    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_cap, out_cap, 8 * N, hipMemcpyHostToDevice, s_up));
+    struct Range {
+        uint32_t lo, hi;
+        uint64_t ilo, ihi, olo, ohi;
+    };
+    std::vector<Range> rg(nchunk);
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        Range &r = rg[c];
+        r.lo = (uint32_t)((uint64_t)n * c / nchunk);
+        r.hi = (uint32_t)((uint64_t)n * (c + 1) / nchunk);
+        r.ilo = r.olo = ~0ull;
+        r.ihi = r.ohi = 0;
+        for (uint32_t i = r.lo; i < r.hi; ++i) {
+            if (in_off[i] < r.ilo) r.ilo = in_off[i];
+            if (in_off[i] + in_len[i] > r.ihi) r.ihi = in_off[i] + in_len[i];
+            if (out_off[i] < r.olo) r.olo = out_off[i];
+            if (out_off[i] + out_cap[i] > r.ohi) r.ohi = out_off[i] + out_cap[i];
         }
     }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    for (uint32_t c = 0; c < nchunk; ++c) {
+        const Range &r = rg[c];
+        const size_t lo = r.lo, m = r.hi - r.lo;
+        if (r.ihi > r.ilo)
+            HIP_TRY(ctx, hipMemcpyAsync(d_in + (r.ilo - in_lo), in_base + r.ilo, r.ihi - r.ilo, hipMemcpyHostToDevice, s_up));
+        if (nchunk > 1) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_up[c], s_up));
+            HIP_TRY(ctx, hipStreamWaitEvent(s_k, ctx->ev_up[c], 0));
+        }
+        pzg::InflateArgs a{};
+        a.in_base = d_in - in_lo;  // offsets stay the caller's
+        a.out_base = d_out - out_lo;
+        a.in_off = (const uint64_t *)(d_meta + m_in_off) + lo;
+        a.in_len = (const uint64_t *)(d_meta + m_in_len) + lo;
+        a.out_off = (const uint64_t *)(d_meta + m_out_off) + lo;
+        a.out_cap = (const uint64_t *)(d_meta + m_out_cap) + lo;
+        a.out_len = (uint64_t *)(d_meta + m_out_len) + lo;
+        a.in_used = (uint64_t *)(d_meta + m_in_used) + lo;
+        a.status = (int32_t *)(d_meta + m_status) + lo;
+        a.adler = (uint32_t *)(d_meta + m_adler) + lo;
+        a.detail = (uint32_t *)(d_meta + m_detail) + 2 * lo;
+        a.order = nullptr;
+        a.prof_out = nullptr;
+#if defined(PZG_PROFILE)
+        a.prof_out = (uint64_t *)ctx->prof_buf;
+#endif
+        a.n = (uint32_t)m;
+        if (flags & PZG_GZIP) {
+            a.gzip = 1;
+            a.gz_expect = (uint32_t *)ctx->a_gz.p + 2 * lo;
+        }
+        a.counter = (uint32_t *)ctx->d_counter;
+        if (c == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev0, s_k));
+        HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, ctx->num_cus, s_k));
+        if (c + 1 == nchunk) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev1, s_k));
+            ctx->timed = true;
+        }
+        if (nchunk > 1) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_k[c], s_k));
+            HIP_TRY(ctx, hipStreamWaitEvent(s_dn, ctx->ev_k[c], 0));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(out_len + lo, a.out_len, 8 * m, hipMemcpyDeviceToHost, s_dn));
+        HIP_TRY(ctx, hipMemcpyAsync(status + lo, a.status, 4 * m, hipMemcpyDeviceToHost, s_dn));
+        if (in_used) HIP_TRY(ctx, hipMemcpyAsync(in_used + lo, a.in_used, 8 * m, hipMemcpyDeviceToHost, s_dn));
+        if (adler) HIP_TRY(ctx, hipMemcpyAsync(adler + lo, a.adler, 4 * m, hipMemcpyDeviceToHost, s_dn));
+        if (detail) HIP_TRY(ctx, hipMemcpyAsync(detail + 2 * lo, a.detail, 8 * m, hipMemcpyDeviceToHost, s_dn));
+        // one D2H transfer of the range's covering bytes into pinned staging
+        if (r.ohi > r.olo)
+            HIP_TRY(ctx, hipMemcpyAsync(stage + (r.olo - out_lo), d_out + (r.olo - out_lo), r.ohi - r.olo, hipMemcpyDeviceToHost, s_dn));
+        if (nchunk > 1) HIP_TRY(ctx, hipEventRecord(ctx->ev_dn[c], s_dn));
+        // while that is in flight: hand the previous range to the caller
+        if (nchunk > 1 && c >= 1) {
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_dn[c - 1]));
+            if (out_bytes) copy_out(rg[c - 1].lo, rg[c - 1].hi);
+        }
+    }
+    if (nchunk > 1) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_dn[nchunk - 1]));
+    } else {
+        HIP_TRY(ctx, hipStreamSynchronize(s_dn));
+    }
+    if (out_bytes) copy_out(rg[nchunk - 1].lo, rg[nchunk - 1].hi);
+    HIP_TRY(ctx, hipStreamSynchronize(s_k));
+    if (trace)
+        fprintf(stderr, "[pzg] host path: %u streams, %.1f MiB in, %.1f MiB out, %u range(s), %u copy thread(s): %.1f ms\n", n,
+                in_bytes / 1048576.0, out_bytes / 1048576.0, nchunk, cthreads,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count());
     return PZG_RC_OK;
 }
 
