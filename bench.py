@@ -280,7 +280,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"inflate_kernel<{ring_bits},false>",
+                "kernel": f"inflate_kernel<{ring_bits},false,{str(bool(args.gzip)).lower()}>",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
