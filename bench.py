@@ -63,6 +63,10 @@ def build_pool(args):
         elif args.workload == "skewed_bytes":  # literal-heavy, many codes longer than the primary table
             t = corpus.skewed_bytes(args.blob_bytes, seed)
             z = zlib.compress(t, args.level)
+        elif args.workload == "fixed_bin":  # fixed-Huffman blocks whose literals are all >= 144: 9-bit codes
+            t = bytes(b | 0x80 for b in corpus.zipf_text(4096, seed))
+            co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+            z = co.compress(t) + co.flush()
         elif args.workload == "runs":  # overlapping matches: byte runs and short repeating patterns (dist < len)
             t = corpus.mixed_data(args.blob_bytes, 2 + (seed & 1) + 4 * seed)
             z = zlib.compress(t, args.level)
@@ -89,7 +93,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed", "skewed_bytes", "html", "runs"])
+    ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed", "skewed_bytes", "html", "runs", "fixed_bin"])
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
     ap.add_argument("--blob-bytes", type=int, default=32768)
     ap.add_argument("--level", type=int, default=6)
@@ -269,6 +273,7 @@ def main():
                     "fixed_4k": f"BASELINE config 3: {args.streams} x 4 KiB fixed-Huffman (Z_FIXED level-1) blobs per GPU",
                     "mixed": f"BASELINE config 5 shape: {args.streams} mixed 1-64 KiB level-6 blobs per GPU",
                     "skewed_bytes": f"diagnostic: {args.streams} x {args.blob_bytes // 1024} KiB literal-heavy skewed-byte blobs, level {args.level}",
+                    "fixed_bin": f"diagnostic: {args.streams} x 4 KiB fixed-Huffman blobs of text with the high bit set (every literal a 9-bit code)",
                     "runs": f"diagnostic: {args.streams} x {args.blob_bytes // 1024} KiB byte runs / short repeating patterns (overlapping matches), level {args.level}",
                     "html": f"diagnostic: {args.streams} x {args.blob_bytes // 1024} KiB slices of the reference's RFC html fixtures, level {args.level}",
                 }[args.workload],

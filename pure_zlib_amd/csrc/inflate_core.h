@@ -1309,6 +1309,7 @@ struct Decoder {
         dist_n = 32u;
         if (uni(L.fixed_ready) == FIXED_MAGIC) {  // still there from an earlier block or stream of this wave
             lit_e15 = dist_e15 = 32768u;
+            use_sub = 1u;  // as build_table() left it when the tables were built (see below)
             return;
         }
         const uint32_t lane = lane_id();
@@ -1320,10 +1321,10 @@ struct Decoder {
         build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, &L.lit_meta, &lit_e15);
         build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, &L.dist_meta, &dist_e15);
         if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = FIXED_MAGIC;
-        // Not a Huffman-optimal code: how often its 9-bit literals (144..255) occur is up to the data, and in text
-        // they do not.  The windows skip the second-level lookup for fixed blocks (as on the cached path above);
-        // a long literal ends the walk and the checked path resolves it through the same tables.
-        use_sub = 0u;
+        // (use_sub = 1 from build_table(): the fixed code has 56 long prefixes -- literals 144..255 are 9 bits.  It
+        // is not a Huffman-optimal code, so how often they occur is up to the data: in plain text never, where the
+        // windows' second lookup costs 4 %; in binary data all the time, where leaving them to the checked path
+        // costs 7x.  The lookup stays on.)
         wave_sync();
     }
 
