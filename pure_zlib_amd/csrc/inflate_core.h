@@ -8,12 +8,13 @@
 //   Deflate.hs:124-156 getCodeLengths       -> dynamic_header()
 //   Deflate.hs:160-237 length/distance arrays -> litlen_entry()/dist_entry() (closed forms)
 //   Deflate.hs:255-292 computeCodeValues    -> build_table() (canonical codes, wave-parallel)
-//   HuffmanTree.hs     binary trie          -> two-level LDS table: a direct 2^P LUT indexed by the
-//                                             next P stream bits, then a canonical first-code/count
-//                                             walk + ballot scan of the code lengths for codes longer than P
+//   HuffmanTree.hs     binary trie          -> multi-level LDS table: a direct 2^P LUT indexed by the next P stream
+//                                             bits, second-level tables for codes longer than P, and behind
+//                                             them an exact canonical first-code walk + ballot scan of the lengths
 //   Monad.hs:203-307   bit/byte reader      -> BitReader: coalesced dword chunks held one dword per
 //                                             lane, a per-wave bit cursor, v_readlane to fetch
-//   OutputWindow.hs    128 KiB flat window  -> 2^RING_BITS LDS ring, lane-cooperative LZ77 copy
+//   OutputWindow.hs    128 KiB flat window  -> 2^RING_BITS LDS ring (+ far reads of the stream's own flushed output when
+//                                             RING_BITS < 15), lane-cooperative LZ77 copy
 //   Adler32.hs         per-byte checksum    -> folded into the ring->HBM flush as a wave reduction
 //
 // The hot loop is wave-parallel: lane k speculatively decodes the complete tokens (literal, or
