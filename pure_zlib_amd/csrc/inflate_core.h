@@ -141,8 +141,15 @@ struct TreeMeta {          // second-level (canonical) decode tables, index = co
     uint16_t first[16];    // first canonical code of that length
 };
 
+#ifndef PZG_DMA_PREFETCH
+#define PZG_DMA_PREFETCH 1
+#endif
+
 template <int RING_BITS>
 struct alignas(16) WaveLds {
+#if PZG_DMA_PREFETCH
+    uint32_t pf[64];                     // input prefetch, written by global_load_lds (must stay the first member: LDS offset 0)
+#endif
     uint8_t ring[1u << RING_BITS];       // OutputWindow: the last 2^RING_BITS bytes produced
     uint32_t lit_lut[1u << LIT_BITS];    // HuffmanTree (literal/length), level 1
     uint32_t dist_lut[1u << DIST_BITS];  // HuffmanTree (distance), level 1; the code-length LUT while a header is read
@@ -181,6 +188,25 @@ struct BitReader {
 #if PZG_DEVICE_PASS
     uint32_t chunk0;       // dword index held by lane 0 of `cur` (multiple of 64)
     uint32_t cur, nxt;     // per-lane
+#if PZG_DMA_PREFETCH
+    // Two chunks ahead: the chunk after `nxt` is fetched straight into LDS (global_load_lds: no VGPR, so no
+    // register copy can force a wait for it) and picked up one slide later.
+    const volatile uint32_t *pf;  // WaveLds::pf (LDS offset 0)
+    PZG_FN void dma_prefetch(uint32_t c0) const
+    {
+        if (c0 >= ndw) return;  // wave-uniform
+        const uint32_t i = c0 + lane_id();
+        const uint32_t *p = base + (i < ndw ? i : ndw - 1u);
+        asm volatile("s_mov_b32 m0, 0\n\tglobal_load_lds_dword %0, off" ::"v"(p) : "memory");  // (m0 is reserved by the compiler, never live across statements here)
+    }
+    PZG_FN uint32_t take_prefetch() const
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t v = pf[lane_id()];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the buffer is free again before the next fetch is issued
+        return v;
+    }
+#endif
 #endif
 
     PZG_FN uint32_t load_dw(uint32_t i) const { return i < ndw ? base[i] : 0u; }
@@ -215,6 +241,9 @@ struct BitReader {
         chunk0 = 0;
         cur = load_chunk(0u);
         nxt = load_chunk_raw(64u);  // masked when it becomes `cur`
+#if PZG_DMA_PREFETCH
+        dma_prefetch(128u);
+#endif
 #endif
     }
 
@@ -236,7 +265,12 @@ struct BitReader {
         while ((uint32_t)(pos >> 5) - chunk0 >= 64u) {
             chunk0 += 64u;
             cur = zero_past_end(nxt, chunk0);
+#if PZG_DMA_PREFETCH
+            nxt = take_prefetch();
+            dma_prefetch(chunk0 + 128u);
+#else
             nxt = load_chunk_raw(chunk0 + 64u);
+#endif
         }
 #endif
     }
@@ -275,7 +309,12 @@ struct BitReader {
         if ((uint32_t)(pos >> 5) - chunk0 >= 64u) {
             chunk0 += 64u;
             cur = zero_past_end(nxt, chunk0);
+#if PZG_DMA_PREFETCH
+            nxt = take_prefetch();
+            dma_prefetch(chunk0 + 128u);
+#else
             nxt = load_chunk_raw(chunk0 + 64u);
+#endif
         }
 #endif
     }
@@ -1433,11 +1472,17 @@ struct Decoder {
         status = ST_OK;
         detail0 = detail1 = 0;
         in_byte0 = 0;
+#if PZG_DEVICE_PASS && PZG_DMA_PREFETCH
+        br.pf = L.pf;
+#endif
         br.start(in, in_len, 0);
         PZG_T0(tall);
         if (in_len >> 34) fail(ST_TRUNCATED, 0, 0);  // the reader indexes dwords with 32 bits: 16 GiB per stream (include/pzg.h)
         else decode();
         PZG_ACC(0, tall);
+#if PZG_DEVICE_PASS && PZG_DMA_PREFETCH
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no fetch into this wave's LDS may outlive the stream
+#endif
         uint64_t used_bits = stream_bit_pos();
         uint64_t used = (used_bits + 7u) >> 3;
         if (used > in_len) used = in_len;
