@@ -278,15 +278,11 @@ struct BitReader {
     PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos; }
     // cheap sufficient test for avail() >= 192 (7 whole dwords follow the cursor's dword index)
     PZG_FN bool window_ok() const { return (uint32_t)(pos >> 5) < win_end; }
-    // same for a 128-bit window (10 whole dwords follow), and on the device its eight dwords sit in `cur`
+    // same for a 128-bit window (10 whole dwords follow)
     PZG_FN bool window2_ok() const
     {
         const uint32_t i = (uint32_t)(pos >> 5);
-#if PZG_DEVICE_PASS
-        return i + 3u < win_end && i - chunk0 <= 56u;
-#else
         return i + 3u < win_end;
-#endif
     }
 
     // the next 32 bits (bits past the stream end read as whatever follows; callers check avail())
@@ -1073,14 +1069,26 @@ struct Decoder {
         LaneVec<uint32_t> TB0, TK0, TB1, TK1;
 #if PZG_DEVICE_PASS
         {
-            const uint32_t li = i0 - br.chunk0;  // <= 56 (window2_ok): dwords li .. li + 7 sit in `cur`
+            const uint32_t li = i0 - br.chunk0;  // < 64: the window's dwords li .. li + 7 sit in `cur`, or in `cur` and `nxt`
             const uint32_t q = boff + lane_id();
-            const uint32_t a = (li + (q >> 5)) << 2, r = q & 31u;
-            const uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
-            const uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
-            const uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
-            const uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
-            const uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
+            const uint32_t d = li + (q >> 5), a = d << 2, r = q & 31u;
+            uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
+            uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
+            uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
+            uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
+            uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
+            if (li > 56u) {  // (one window in nine) the same gathers from the next chunk for the dwords past this one
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.nxt);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.nxt);
+                const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.nxt);
+                const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.nxt);
+                const uint32_t n4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.nxt);
+                lo0 = d >= 64u ? n0 : lo0;  // (the crossbar index wraps modulo 64, so dword d of `nxt` is lane d - 64)
+                mid0 = d + 1u >= 64u ? n1 : mid0;
+                hi0 = d + 2u >= 64u ? n2 : hi0;
+                mid1 = d + 3u >= 64u ? n3 : mid1;
+                hi1 = d + 4u >= 64u ? n4 : hi1;
+            }
             decode_pair(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
         }
 #else
