@@ -71,7 +71,10 @@ enum { TREE_CODELEN = 0, TREE_LITLEN = 1, TREE_DIST = 2 };
 #define PZG_LIT_BITS 8
 #endif
 constexpr int LIT_BITS = PZG_LIT_BITS;  // primary literal/length LUT: 2^8 x 4 B = 1 KiB (LDS is what bounds residency)
-constexpr uint32_t SUB_ENTRIES = 188;   // pool of second-level entries for literal/length codes longer than LIT_BITS
+#ifndef PZG_SUB_ENTRIES
+#define PZG_SUB_ENTRIES 188
+#endif
+constexpr uint32_t SUB_ENTRIES = PZG_SUB_ENTRIES;   // pool of second-level entries for literal/length codes longer than LIT_BITS
 constexpr uint32_t SUB_BITS_MAX = 5;    // a second-level table resolves at most this many further bits
 #ifndef PZG_SUB_MIN
 #define PZG_SUB_MIN 3
