@@ -482,6 +482,13 @@ struct Decoder {
     PZG_FN void complete_pending()
     {
         if (pend_run == 0u) return;
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        {
+            PZG_T0(t_w);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PZG_ACC(10, t_w);  // how long the far bytes are waited for
+        }
+#endif
         const uint32_t run = pend_run, op32 = (uint32_t)op;
         const bool has_far = pend_far != 0u;
         PZG_LANES_BEGIN(j)
@@ -1252,7 +1259,6 @@ struct Decoder {
                 PZG_LV(BV, j) = (pj & LIT_FLAG) ? (pj & 0xffu) : g;
             PZG_LANES_END
             pend_far = 0u;
-            PZG_ACCW(10, t_c);
             PZG_T0(t_d);
             if (HYBRID) {  // sources older than the ring: the stream's own flushed output
                 LaneVec<bool> FAR;

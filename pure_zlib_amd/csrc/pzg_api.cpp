@@ -367,7 +367,7 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
         a.order = nullptr;
         a.prof_out = nullptr;
 #if defined(PZG_PROFILE)
-        a.prof_out = (uint64_t *)ctx->prof_buf;
+        a.prof_out = ctx->prof_buf ? (uint64_t *)ctx->prof_buf + 16 * lo : nullptr;
 #endif
         a.n = (uint32_t)m;
         if (flags & PZG_GZIP) {
