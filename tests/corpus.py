@@ -143,7 +143,7 @@ def gzip_member(data: bytes, seed: int) -> bytes:
                           rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_FILTERED]))
     body = co.compress(data) + co.flush()
     flg = rng.randrange(32) & 0x1e
-    hdr = bytearray(b"\x1f\x8b\x08" + bytes([flg]) + struct.pack("<I", seed * 977) + bytes([rng.choice([0, 2, 4]), rng.choice([0, 3, 255])]))
+    hdr = bytearray(b"\x1f\x8b\x08" + bytes([flg]) + struct.pack("<I", (seed * 977) & 0xffffffff) + bytes([rng.choice([0, 2, 4]), rng.choice([0, 3, 255])]))
     if flg & 4:
         extra = bytes(rng.getrandbits(8) for _ in range(rng.randint(0, 40)))
         hdr += struct.pack("<H", len(extra)) + extra
