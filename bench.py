@@ -109,6 +109,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test knobs (tests/test_gpu_fullsize.py runs the N>1 path with two ranks on ONE device): RCCL refuses two ranks
+    # on the same GPU, so that run rendezvous over gloo; the driver's multi-GPU runs use neither knob
+    local_rank = int(os.environ.get("PZG_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("PZG_BENCH_BACKEND", "nccl")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -118,7 +122,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    rdev = dev if backend == "nccl" else torch.device("cpu")  # where the cross-rank scalars live
 
     t_setup = time.time()
     texts, zs = build_pool(args)
@@ -190,7 +198,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -220,7 +228,7 @@ def main():
                     break
         bit_exact = ok
         if world > 1:
-            tt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            tt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=rdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             bit_exact = bool(tt.item())
         if not bit_exact:

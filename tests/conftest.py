@@ -36,6 +36,8 @@ def oracle():
 def gpu_ctx():
     """A pzg context on device 0.  Fails (does not skip) when the HIP extension or the device is
     missing: GPU tests must never pass on a fallback."""
+    import torch  # first: libpzg.so then binds to the HIP runtime torch has already loaded (as in bench.py); the other
+    torch.cuda.init()  # order leaves torch without a device for the tests that keep their arenas in torch tensors
     import pure_zlib_amd as P
     ctx = P.Context(0)
     yield ctx

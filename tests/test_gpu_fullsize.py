@@ -1,0 +1,95 @@
+"""GPU parity at BASELINE.json's FULL sizes, one launch each, through the C ABI with the arenas
+resident in HBM exactly as bench.py's timed region hands them over:
+
+  config 3   65,536 x 4 KiB fixed-Huffman (Z_FIXED, level 1) blobs  -- rings 11 and 15
+  config 5   131,072 mixed 1-64 KiB level-6 blobs = its per-GPU share (1 M streams over 8 GPUs)
+  N > 1      bench.py ITSELF under torch.distributed.run with two ranks (both on device 0, gloo rendezvous:
+             RCCL refuses two ranks on one GPU): the sharding, the barrier, MAX of the time, MIN of bit_exact
+
+Every stream: status, length, in_used, Adler-32 against zlib.adler32, every decoded byte against the text it was
+compressed from, and 256 sampled streams against the oracle (the restatement of the reference)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+from conftest import ROOT
+from devbatch import DeviceBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixed_pool(npool):
+    texts, zs = [], []
+    for seed in range(npool):
+        t = corpus.zipf_text(4096, seed)
+        co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        texts.append(t)
+        zs.append(co.compress(t) + co.flush())
+    return texts, zs
+
+
+def test_config3_65536_fixed_huffman_4k_blobs(gpu_ctx, oracle):
+    """BASELINE config 3 at full size.  A persistent wave decodes ~10 streams back to back here, so the
+    fixed tables built once per wave (WaveLds::fixed_ready) are reused across streams."""
+    texts, zs = _fixed_pool(1024)
+    assert all((z[2] >> 1) & 3 == 1 for z in zs)  # BTYPE 01: fixed Huffman
+    pick = np.random.default_rng(0xC3).integers(0, len(zs), size=65536)
+    b = DeviceBatch(texts, zs, pick)
+    for ring in (11, 15):
+        res = b.run(gpu_ctx, ring)
+        b.check_all(*res)
+        b.check_sample_vs_oracle(oracle, 256)
+    gpu_ctx.set_ring_bits(11)
+
+
+def test_config5_per_gpu_share_131072_mixed_blobs(gpu_ctx, oracle):
+    """BASELINE config 5's per-GPU share: 1 M mixed 1-64 KiB level-6 blobs over 8 GPUs = 131,072 per GPU
+    (4 GiB decoded per launch), laid out longest first as the sharder hands a shard over."""
+    from pure_zlib_amd.shard import plan_shards
+    texts, zs = [], []
+    for seed in range(1024):
+        size = 1024 * (1 + (seed * 2654435761 >> 7) % 64)
+        t = corpus.zipf_text(size, seed)
+        texts.append(t)
+        zs.append(zlib.compress(t, 6))
+    assert {len(t) for t in texts} == {1024 * k for k in range(1, 65)}
+    perm = np.random.default_rng(0xC5).integers(0, len(zs), size=1 << 20)  # the whole node's batch
+    dec_len = np.array([len(t) for t in texts], dtype=np.int64)
+    shards = plan_shards(dec_len[perm], 8)
+    mine = shards[3]
+    assert abs(len(mine) - 131072) < 2048
+    b = DeviceBatch(texts, zs, perm[mine])
+    res = b.run(gpu_ctx, 11)
+    b.check_all(*res)
+    b.check_sample_vs_oracle(oracle, 256)
+
+
+def test_bench_py_two_ranks_on_one_device():
+    """The real N>1 path of bench.py: torch.distributed.run launches two ranks before anything touches the GPU; each
+    decodes its own shard through libpzg.so, the time is MAX-reduced, bit_exact MIN-reduced, rank 0 prints the line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+               PZG_BENCH_DEVICE="0", PZG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--streams", "4096", "--pool", "256"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # ONE line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["bit_exact"] is True and r["scaling"] == "weak"
+    assert r["config"]["streams_per_gpu"] == 4096 and r["config"]["parallelism"] == "shard2"
+    # whole-job value: both ranks' bytes over the max-over-ranks time
+    assert abs(r["value"] - 2 * 4096 * 32768 / (r["ms_per_step"] * 1e-3) / 2**30) / r["value"] < 0.02
+    assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
