@@ -88,55 +88,76 @@ constexpr int MAX_LIT_SYMS = 288;        // HLIT <= 288
 constexpr int MAX_DIST_SYMS = 32 + 138;  // HDIST <= 32 plus a code-length repeat overrun (Deflate.hs:132)
 constexpr int MAX_LENS = 288 + 32 + 138;
 
-// LUT entry: [4:0] code bits n  [8:5] extra bits e  [11:9] kind  [31:16] value
+// LUT entries (literal/length, distance, second-level and code-length tables), 32 bits.  The layout is what the
+// windows' speculative decode (spec_finish) needs in the fewest vector instructions: a shift or bit-field
+// operand is the low five bits of a register, so every field that is used as one starts a byte.
+//   token entries (bit 7 clear)
+//     literal         [4:0] n              [15:8] byte   [24:16] 1                   -- the queued token itself
+//     length base     [4:0] n + extra bits [12:8] n      [24:16] base length  [31] 1
+//     distance base   [4:0] n + extra bits [12:8] n      [31:16] base distance
+//     code-length sym [4:0] n              [12:8] extra bits          [31:16] symbol (dynamic_header only)
+//   stoppers (bit 7 set): a window's walk ends there and token_step_checked() takes over
+//     [4:0] n  [7] 1  [11:8] kind  [30:16] value
 enum : uint32_t {
-    K_LIT = 0,           // value = literal byte (or code-length symbol)
-    K_BASE = 1,          // value = base length / base distance, e extra bits follow
+    K_LIT = 0,           // (token entry, bit 31 clear) literal byte or code-length symbol
+    K_BASE = 1,          // (token entry) base length (bit 31 set) / base distance, extra bits follow
     K_EOB = 2,           // symbol 256
-    K_LONG = 3,          // code longer than the primary table: second level
+    K_LONG = 3,          // code longer than the tables resolve: decode_long()
     K_EMPTY_BRANCH = 4,  // n = depth at which the reference's walk reaches HuffmanEmpty
     K_EMPTY_TREE = 5,    // the tree has no codes at all
     K_BADSYM = 6,        // symbol 286/287 or distance symbol >= 30: value = symbol
     K_SUB = 7            // second-level table at sub[value], indexed by the next n bits
 };
+constexpr uint32_t ENT_STOP = 0x80u;  // bit 7: the byte sum tb of spec_finish() is then >= 128, which the walk tests for
+constexpr uint32_t ENT_MATCH = 0x80000000u;
 
-PZG_FN uint32_t mk_entry(uint32_t n, uint32_t e, uint32_t kind, uint32_t value)
-{
-    return n | (e << 5) | (kind << 9) | (value << 16);
-}
-PZG_FN uint32_t ent_n(uint32_t x) { return x & 31u; }
-PZG_FN uint32_t ent_e(uint32_t x) { return (x >> 5) & 15u; }
-PZG_FN uint32_t ent_kind(uint32_t x) { return (x >> 9) & 7u; }
-PZG_FN uint32_t ent_val(uint32_t x) { return x >> 16; }
+PZG_FN uint32_t mk_stop(uint32_t n, uint32_t kind, uint32_t value) { return n | ENT_STOP | (kind << 8) | (value << 16); }
+PZG_FN bool ent_is_stop(uint32_t x) { return (x & ENT_STOP) != 0u; }
+PZG_FN uint32_t ent_stop_kind(uint32_t x) { return (x >> 8) & 15u; }   // stoppers only
+PZG_FN uint32_t ent_n(uint32_t x) { return x & 31u; }                   // stoppers, literals, code-length symbols
+PZG_FN uint32_t ent_val(uint32_t x) { return x >> 16; }                 // stoppers (value), distance base, code-length symbol
+PZG_FN uint32_t ent_base_n(uint32_t x) { return (x >> 8) & 31u; }       // length / distance base: code bits
+PZG_FN uint32_t ent_base_tot(uint32_t x) { return x & 31u; }            // ... code bits + extra bits
+PZG_FN uint32_t ent_len_base(uint32_t x) { return (x >> 16) & 511u; }   // length base
+PZG_FN uint32_t ent_lit_byte(uint32_t x) { return (x >> 8) & 255u; }
+PZG_FN uint32_t ent_kind_lit(uint32_t x) { return ent_is_stop(x) ? ent_stop_kind(x) : (x & ENT_MATCH) ? (uint32_t)K_BASE : (uint32_t)K_LIT; }
+PZG_FN uint32_t ent_kind_dist(uint32_t x) { return ent_is_stop(x) ? ent_stop_kind(x) : (uint32_t)K_BASE; }
 
 // Deflate.hs:164-196 lengthArray as a closed form: symbol 257..285 -> (base, extra)
 PZG_FN uint32_t litlen_entry(uint32_t sym, uint32_t n)
 {
-    if (sym < 256u) return mk_entry(n, 0, K_LIT, sym);
-    if (sym == 256u) return mk_entry(n, 0, K_EOB, 0);
-    if (sym > 285u) return mk_entry(n, 0, K_BADSYM, sym);
-    uint32_t i = sym - 257u;
-    if (i < 8u) return mk_entry(n, 0, K_BASE, 3u + i);
-    if (i == 28u) return mk_entry(n, 0, K_BASE, 258u);
-    uint32_t e = (i >> 2) - 1u;
-    return mk_entry(n, e, K_BASE, 3u + ((4u + (i & 3u)) << e));
+    if (sym < 256u) return n | (sym << 8) | (1u << 16);
+    if (sym == 256u) return mk_stop(n, K_EOB, 0);
+    if (sym > 285u) return mk_stop(n, K_BADSYM, sym);
+    uint32_t i = sym - 257u, e = 0, base;
+    if (i < 8u) base = 3u + i;
+    else if (i == 28u) base = 258u;
+    else {
+        e = (i >> 2) - 1u;
+        base = 3u + ((4u + (i & 3u)) << e);
+    }
+    return (n + e) | (n << 8) | (base << 16) | ENT_MATCH;
 }
 
 // Deflate.hs:203-237 distanceArray as a closed form: code 0..29 -> (base, extra)
 PZG_FN uint32_t dist_entry(uint32_t sym, uint32_t n)
 {
-    if (sym > 29u) return mk_entry(n, 0, K_BADSYM, sym);
-    if (sym < 4u) return mk_entry(n, 0, K_BASE, 1u + sym);
-    uint32_t e = (sym >> 1) - 1u;
-    return mk_entry(n, e, K_BASE, 1u + ((2u + (sym & 1u)) << e));
+    if (sym > 29u) return mk_stop(n, K_BADSYM, sym);
+    uint32_t e = 0, base = 1u + sym;
+    if (sym >= 4u) {
+        e = (sym >> 1) - 1u;
+        base = 1u + ((2u + (sym & 1u)) << e);
+    }
+    return (n + e) | (n << 8) | (base << 16);
 }
 
 // code-length alphabet (Deflate.hs:131-149): 0..15 literal lengths, 16/17/18 repeats with 2/3/7 extra bits
 PZG_FN uint32_t codelen_entry(uint32_t sym, uint32_t n)
 {
     uint32_t e = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
-    return mk_entry(n, e, K_LIT, sym);
+    return n | (e << 8) | (sym << 16);
 }
+PZG_FN uint32_t ent_cl_extra(uint32_t x) { return (x >> 8) & 15u; }
 
 // ---- LDS image of one wave ------------------------------------------------------------------
 struct TreeMeta {          // second-level (canonical) decode tables, index = code length 1..15
@@ -186,11 +207,13 @@ struct BitReader {
     uint32_t ndw;          // dwords covering [base, stream end)
     uint32_t mis_bits;     // 8 * (stream start - base)
     uint64_t end_rel;      // mis_bits + 8 * stream length: first bit (relative to base) past the stream
-    uint64_t pos;          // next unread bit, relative to base
     uint32_t win_end;      // a cursor in a dword below this index has >= 192 stream bits in front of it
+    // The cursor is kept as (chunk0, rp): the hot loops only ever touch the 32-bit rp.
+    uint32_t chunk0;       // dword index of the 64-dword chunk the cursor is in (a multiple of 64; lane 0 of `cur`)
+    uint32_t rp;           // next unread bit, relative to bit 32 * chunk0; slide() keeps it below 2048
+    int32_t rp_ok1, rp_ok2;  // rp below these (signed): a 64-bit / a 128-bit window may run (set_limits)
 #if PZG_DEVICE_PASS
-    uint32_t chunk0;       // dword index held by lane 0 of `cur` (multiple of 64)
-    uint32_t cur, nxt;     // per-lane
+    uint32_t cur, nxt;     // per-lane: dwords chunk0 + lane and chunk0 + 64 + lane
 #if PZG_DMA_PREFETCH
     // Two chunks ahead: the chunk after `nxt` is fetched straight into LDS (global_load_lds: no VGPR, so no
     // register copy can force a wait for it) and picked up one slide later.
@@ -212,6 +235,8 @@ struct BitReader {
 #endif
 #endif
 
+    PZG_FN uint64_t pos() const { return ((uint64_t)chunk0 << 5) + rp; }  // next unread bit, relative to base
+
     PZG_FN uint32_t load_dw(uint32_t i) const { return i < ndw ? base[i] : 0u; }
 
     // lane l's dword of the 64-dword chunk starting at c0 (wave-uniform), zero past the stream.
@@ -229,6 +254,17 @@ struct BitReader {
     }
     PZG_FN uint32_t zero_past_end(uint32_t v, uint32_t c0) const { return c0 + lane_id() < ndw ? v : 0u; }
 
+    // the window tests, relative to the current chunk (recomputed once per 2048 bits, tested once per window):
+    //   64-bit window   dword index of the cursor     < win_end
+    //   128-bit window  dword index of the cursor + 3 < win_end   (10 whole dwords follow)
+    PZG_FN void set_limits()
+    {
+        int64_t d = (int64_t)win_end - (int64_t)chunk0;
+        d = d > 4096 ? 4096 : d < 0 ? 0 : d;  // (rp stays below 2048 + one window: anything past that is "yes")
+        rp_ok1 = (int32_t)d * 32;
+        rp_ok2 = ((int32_t)d - 3) * 32;
+    }
+
     PZG_FN void start(const uint8_t *in, uint64_t in_len, uint64_t byte_pos)
     {
         const uint8_t *p = in + byte_pos;
@@ -238,10 +274,11 @@ struct BitReader {
         mis_bits = mis * 8u;
         ndw = (uint32_t)((mis + remain + 3u) >> 2);
         end_rel = (uint64_t)mis_bits + remain * 8u;
-        pos = mis_bits;
         win_end = (end_rel >> 5) >= 6u ? (uint32_t)(end_rel >> 5) - 6u : 0u;
-#if PZG_DEVICE_PASS
         chunk0 = 0;
+        rp = mis_bits;
+        set_limits();
+#if PZG_DEVICE_PASS
         cur = load_chunk(0u);
         nxt = load_chunk_raw(64u);  // masked when it becomes `cur`
 #if PZG_DMA_PREFETCH
@@ -261,63 +298,53 @@ struct BitReader {
 #endif
     }
 
+    // one chunk forward
+    PZG_FN void step_chunk()
+    {
+        rp -= 2048u;
+        chunk0 += 64u;
+#if PZG_DEVICE_PASS
+        cur = zero_past_end(nxt, chunk0);
+#if PZG_DMA_PREFETCH
+        nxt = take_prefetch();
+        dma_prefetch(chunk0 + 128u);
+#else
+        nxt = load_chunk_raw(chunk0 + 64u);
+#endif
+#endif
+        set_limits();
+    }
     // keep the cursor's dword inside `cur`
     PZG_FN void slide()
     {
-#if PZG_DEVICE_PASS
-        while ((uint32_t)(pos >> 5) - chunk0 >= 64u) {
-            chunk0 += 64u;
-            cur = zero_past_end(nxt, chunk0);
-#if PZG_DMA_PREFETCH
-            nxt = take_prefetch();
-            dma_prefetch(chunk0 + 128u);
-#else
-            nxt = load_chunk_raw(chunk0 + 64u);
-#endif
-        }
-#endif
+        while (rp >= 2048u) step_chunk();
     }
 
-    PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos; }
+    PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos(); }
     // cheap sufficient test for avail() >= 192 (7 whole dwords follow the cursor's dword index)
-    PZG_FN bool window_ok() const { return (uint32_t)(pos >> 5) < win_end; }
+    PZG_FN bool window_ok() const { return (int32_t)rp < rp_ok1; }
     // same for a 128-bit window (10 whole dwords follow)
-    PZG_FN bool window2_ok() const
-    {
-        const uint32_t i = (uint32_t)(pos >> 5);
-        return i + 3u < win_end;
-    }
+    PZG_FN bool window2_ok() const { return (int32_t)rp < rp_ok2; }
 
     // the next 32 bits (bits past the stream end read as whatever follows; callers check avail())
     PZG_FN uint32_t peek32() const
     {
-        const uint32_t i = (uint32_t)(pos >> 5);
-        return funnel(dword(i + 1u), dword(i), (uint32_t)pos & 31u);
+        const uint32_t i = chunk0 + (rp >> 5);
+        return funnel_uniform(dword(i + 1u), dword(i), rp & 31u);
     }
     PZG_FN void drop(uint32_t n)
     {
-        pos += n;
+        rp += n;
         slide();
     }
     // drop() for n < 2048 from a cursor slide() has already placed: at most one chunk step, written
     // without a loop so the prefetch into `nxt` stays an outstanding load (no copy of it is needed).
     PZG_FN void drop_short(uint32_t n)
     {
-        pos += n;
-#if PZG_DEVICE_PASS
-        if ((uint32_t)(pos >> 5) - chunk0 >= 64u) {
-            chunk0 += 64u;
-            cur = zero_past_end(nxt, chunk0);
-#if PZG_DMA_PREFETCH
-            nxt = take_prefetch();
-            dma_prefetch(chunk0 + 128u);
-#else
-            nxt = load_chunk_raw(chunk0 + 64u);
-#endif
-        }
-#endif
+        rp += n;
+        if (rp >= 2048u) step_chunk();
     }
-    PZG_FN void align_to_byte() { drop((uint32_t)(8u - ((uint32_t)pos & 7u)) & 7u); }
+    PZG_FN void align_to_byte() { drop((8u - (rp & 7u)) & 7u); }  // (32 * chunk0 is a multiple of 8)
 };
 
 // ---- decoder state (all wave-uniform) -----------------------------------------------------------
@@ -366,7 +393,9 @@ struct Decoder {
     PZG_FN void pin_uniform()
     {
 #if PZG_DEVICE_PASS
-        br.pos = uni64(br.pos);
+        br.rp = uni(br.rp);
+        br.rp_ok1 = (int32_t)uni((uint32_t)br.rp_ok1);
+        br.rp_ok2 = (int32_t)uni((uint32_t)br.rp_ok2);
         br.chunk0 = uni(br.chunk0);
         br.end_rel = uni64(br.end_rel);
         br.ndw = uni(br.ndw);
@@ -399,7 +428,7 @@ struct Decoder {
     }
 
     // absolute bit offset of the next unread bit within the stream
-    PZG_FN uint64_t stream_bit_pos() const { return in_byte0 * 8u + br.pos - br.mis_bits; }
+    PZG_FN uint64_t stream_bit_pos() const { return in_byte0 * 8u + br.pos() - br.mis_bits; }
 
     // ---- OutputWindow.hs + Adler32.hs: ring -> HBM flush with the checksum folded in ------------
     // Writes produced bytes [flushed, to) and advances the Adler state over them.  `flushed` is
@@ -686,7 +715,7 @@ struct Decoder {
 #pragma nounroll
             for (uint32_t i0 = 0; i0 < (np_fit << sb); i0 += PZG_WAVE) {
                 const uint32_t i = i0 + lane;
-                if (i < (np_fit << sb)) L.sub[sub0 + i] = mk_entry(0, 0, K_LONG, 0);
+                if (i < (np_fit << sb)) L.sub[sub0 + i] = mk_stop(0, K_LONG, 0);
             }
         }
         wave_sync();
@@ -700,16 +729,16 @@ struct Decoder {
                 const uint32_t c_p = bitrev32(idx) >> (32u - P);  // MSB-first value of the P stream bits
                 uint32_t ent;
                 if (e15 == 0u) {
-                    ent = mk_entry(1, 0, K_EMPTY_TREE, 0);
+                    ent = mk_stop(1, K_EMPTY_TREE, 0);
                 } else if ((c_p << (15u - P)) < e15) {
-                    ent = (TREE != TREE_CODELEN && c_p - covered_p < np_fit) ? mk_entry(sb, 0, K_SUB, sub0 + ((c_p - covered_p) << sb))
-                                                                           : mk_entry(0, 0, K_LONG, 0);
+                    ent = (TREE != TREE_CODELEN && c_p - covered_p < np_fit) ? mk_stop(sb, K_SUB, sub0 + ((c_p - covered_p) << sb))
+                                                                           : mk_stop(0, K_LONG, 0);
                 } else {
                     uint32_t d = (uint32_t)P;  // smallest d whose d-bit prefix is at or past the end of all codes
 #pragma unroll
                     for (uint32_t t = (uint32_t)P - 1u; t >= 1u; --t)
                         if (((c_p >> ((uint32_t)P - t)) << (15u - t)) >= e15) d = t;
-                    ent = mk_entry(d, 0, K_EMPTY_BRANCH, 0);
+                    ent = mk_stop(d, K_EMPTY_BRANCH, 0);
                 }
                 if (idx < (1u << P) && c_p >= covered_p) lut[idx] = ent;
             }
@@ -796,16 +825,16 @@ struct Decoder {
                 }
                 return TREE == TREE_LITLEN ? litlen_entry(sym, l) : dist_entry(sym, l);
             }
-            if ((code << (15u - l)) >= e15) return mk_entry(l, 0, K_EMPTY_BRANCH, 0);
+            if ((code << (15u - l)) >= e15) return mk_stop(l, K_EMPTY_BRANCH, 0);
         }
-        return mk_entry(15, 0, K_EMPTY_BRANCH, 0);  // unreachable: e15 <= 2^15 ends every walk by 15
+        return mk_stop(15, K_EMPTY_BRANCH, 0);  // unreachable: e15 <= 2^15 ends every walk by 15
     }
 
     // Checks a non-symbol entry against the real bits left, in the reference's order: the walk
     // runs out of data (TRUNCATED) before any error that needs a later bit.
     PZG_FN int check_entry(uint32_t ent)
     {
-        const uint32_t kind = ent_kind(ent);
+        const uint32_t kind = ent_is_stop(ent) ? ent_stop_kind(ent) : (uint32_t)K_LIT;
         const int64_t av = br.avail();
         if (kind == K_EMPTY_TREE) {
             // nextCode reads one bit, then advanceTree fails (Monad.hs:297-299, HuffmanTree.hs:76)
@@ -821,8 +850,9 @@ struct Decoder {
     }
 
     // ---- the wave's token queue (see window_append / emit_segment below) ---------------------------
-    // A queued token is one dword:  literal  LIT_FLAG | 1 << 16 | byte      match  len << 16 | dist.
-    static constexpr uint32_t LIT_FLAG = 0x80000000u;
+    // A queued token is one dword:  match  TK_MATCH | len << 16 | dist      literal  1 << 16 | byte << 8 | (junk in [7:0])
+    // -- a literal's token is its LUT entry as it stands, so the windows spend no instruction on it.
+    static constexpr uint32_t TK_MATCH = ENT_MATCH;
     static constexpr uint32_t QCAP = 63u;   // queue lanes 0..62; lane 63 receives what the compaction discards
 #ifndef PZG_QHIGH
 #define PZG_QHIGH 40
@@ -847,48 +877,48 @@ struct Decoder {
     {
         uint32_t bits = br.peek32();
         uint32_t e = uni(L.lit_lut[bits & ((1u << LIT_BITS) - 1u)]);
-        uint32_t kind = ent_kind(e);
+        uint32_t kind = ent_kind_lit(e);
         if (kind == K_SUB) {  // second level: one more (wave-uniform) lookup
             e = uni(L.sub[ent_val(e) + ((bits >> LIT_BITS) & ((1u << ent_n(e)) - 1u))]);
-            kind = ent_kind(e);
+            kind = ent_kind_lit(e);
         }
         if (kind == K_LONG) {  // the exact walk for whatever the tables do not hold
             e = decode_long<TREE_LITLEN>(bits, &L.lit_meta, L.lens, lit_n, lit_e15);
-            kind = ent_kind(e);
+            kind = ent_kind_lit(e);
         }
         if (kind == K_LIT) {
             const uint32_t n = ent_n(e);
             if (br.avail() < (int64_t)n) return fail(ST_TRUNCATED, 0, 0);
             br.drop(n);
-            queue_push(LIT_FLAG | (1u << 16) | (ent_val(e) & 0xffu));
+            queue_push(e);
             return ST_OK;
         }
         if (kind == K_BASE) {
-            const uint32_t n = ent_n(e), ex = ent_e(e);
-            if (br.avail() < (int64_t)(n + ex)) return fail(ST_TRUNCATED, 0, 0);
-            const uint32_t len = ent_val(e) + ((bits >> n) & ((1u << ex) - 1u));
-            br.drop(n + ex);
+            const uint32_t n = ent_base_n(e), tot = ent_base_tot(e);
+            if (br.avail() < (int64_t)tot) return fail(ST_TRUNCATED, 0, 0);
+            const uint32_t len = ent_len_base(e) + ((bits >> n) & ((1u << (tot - n)) - 1u));
+            br.drop(tot);
             bits = br.peek32();
             uint32_t d = uni(L.dist_lut[bits & ((1u << DIST_BITS) - 1u)]);
-            uint32_t dk = ent_kind(d);
+            uint32_t dk = ent_kind_dist(d);
             if (dk == K_SUB) {
                 d = uni(L.sub[ent_val(d) + ((bits >> DIST_BITS) & ((1u << ent_n(d)) - 1u))]);
-                dk = ent_kind(d);
+                dk = ent_kind_dist(d);
             }
             if (dk == K_LONG) {
                 d = decode_long<TREE_DIST>(bits, &L.dist_meta, L.lens + lit_n, dist_n, dist_e15);
-                dk = ent_kind(d);
+                dk = ent_kind_dist(d);
             }
             if (dk != K_BASE) {
                 if (int st = check_entry(d)) return st;
                 // K_BADSYM: distanceArray ! c out of range, the reference throws (Deflate.hs:199-205)
                 return fail(ST_BAD_DIST_SYMBOL, ent_val(d), 0);
             }
-            const uint32_t dn = ent_n(d), dex = ent_e(d);
-            if (br.avail() < (int64_t)(dn + dex)) return fail(ST_TRUNCATED, 0, 0);
-            const uint32_t dist = ent_val(d) + ((bits >> dn) & ((1u << dex) - 1u));
-            br.drop(dn + dex);
-            queue_push((len << 16) | dist);  // emit_segment() checks the distance against what has been produced by then
+            const uint32_t dn = ent_base_n(d), dtot = ent_base_tot(d);
+            if (br.avail() < (int64_t)dtot) return fail(ST_TRUNCATED, 0, 0);
+            const uint32_t dist = ent_val(d) + ((bits >> dn) & ((1u << (dtot - dn)) - 1u));
+            br.drop(dtot);
+            queue_push(TK_MATCH | (len << 16) | dist);  // emit_segment() checks the distance against what has been produced by then
             return ST_OK;
         }
         if (int st = check_entry(e)) return st;
@@ -929,32 +959,29 @@ struct Decoder {
     }
     PZG_FN void spec_sub(Spec &t)
     {
-        const bool is_sub = ent_kind(t.e) == K_SUB;
+        const bool is_sub = (t.e & (ENT_STOP | (15u << 8))) == (ENT_STOP | ((uint32_t)K_SUB << 8));
         const uint32_t i2 = is_sub ? ent_val(t.e) + ((t.w_lo >> LIT_BITS) & ((1u << ent_n(t.e)) - 1u)) : 0u;
         const uint32_t e2 = L.sub[i2];
         t.e = is_sub ? e2 : t.e;
     }
     PZG_FN void spec_dist(Spec &t)
     {
-        t.w2 = funnel(t.w_hi, t.w_lo, ent_n(t.e) + ent_e(t.e));  // bits after the length code (<= 20 in)
+        t.w2 = funnel(t.w_hi, t.w_lo, t.e);  // bits after the length code and its extra bits: the entry's [4:0], <= 20
         t.d = L.dist_lut[t.w2 & ((1u << DIST_BITS) - 1u)];
     }
-    // tb = the token's length in bits, 64 if it is not a plain literal/match (the walk stops there); tk = the token
+    // tb = the token's length in bits, >= 128 if it is not a plain literal/match (the walk stops there); tk = the token.
+    // The entry layout (see the top of this file) makes this 14 vector instructions: a literal's entry IS its token, a
+    // match's token is the two entries' high halves side by side plus the two extra-bit fields, and tb is a byte sum.
     PZG_FN void spec_finish(const Spec &t, uint32_t &tb, uint32_t &tk)
     {
         const uint32_t e = t.e, d = t.d;
-        const uint32_t n = ent_n(e), ex = ent_e(e), kind = ent_kind(e);
-        const uint32_t lenv = ent_val(e) + ((t.w_lo >> n) & ((1u << ex) - 1u));  // literal byte when kind == K_LIT
-        const uint32_t dn = ent_n(d), dex = ent_e(d);                            // n + ex <= 20, dn + dex <= 28
-        const uint32_t dist = ent_val(d) + ((t.w2 >> dn) & ((1u << dex) - 1u));
-        const bool is_lit = kind == K_LIT;
-        const bool is_match = kind == K_BASE && ent_kind(d) == K_BASE;
-        uint32_t tk_match = (lenv << 16) | dist;
-#if PZG_DEVICE_PASS
-        asm("" : "+v"(tk_match));  // keep the match arithmetic out of a lane-dependent branch (straight-line code)
-#endif
-        tb = is_lit ? n : is_match ? n + ex + dn + dex : 64u;
-        tk = is_lit ? (LIT_FLAG | (1u << 16) | (lenv & 0xffu)) : is_match ? tk_match : 0u;
+        const uint32_t en = e >> 8, dn = d >> 8;              // [4:0] = code bits
+        const uint32_t xl = ubfe(t.w_lo, en, e - en);         // length extra bits:   width = (n + extra) - n  (mod 32)
+        const uint32_t xd = ubfe(t.w2, dn, d - dn);           // distance extra bits
+        const uint32_t tk_match = hi_halves(e, d) + ((xl << 16) + xd);  // TK_MATCH | (base len + xl) << 16 | (base dist + xd): no carries
+        const uint32_t m = (uint32_t)((int32_t)e >> 31);      // all ones: a length entry, the distance entry counts
+        tb = (e + (d & m)) & 0xffu;                           // byte sums: either stop bit (0x80) pushes it to >= 128
+        tk = (tk_match & m) | (e & ~m);
     }
     PZG_FN void decode_at(uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r, uint32_t &tb, uint32_t &tk)
     {
@@ -981,106 +1008,112 @@ struct Decoder {
         spec_finish(b, tb1, tk1);
     }
 
-    // Precondition: at least WINDOW_MIN_BITS real bits follow the cursor, so every token that
+    // ---- phase B (scalar): follow the real chain through one 64-offset half --------------------------------
+    // S collects the offsets visited from k on (the token starts); returns where the chain leaves the half: an offset
+    // >= 64, and >= 128 exactly when it ran into a stopper (a stopper's tb has bit 7 set; a token's is at most 48).
+    // The only serial part of the decode: one v_readlane, three SALU ops and a branch per token.
+    PZG_FN uint32_t walk_half(const LaneVec<uint32_t> &TB, uint32_t k, uint64_t &S)
+    {
+        do {
+#if PZG_DEVICE_PASS
+            asm("s_bitset1_b64 %0, %1" : "+s"(S) : "s"(k));  // S |= 1 << k in one SALU op
+#else
+            S |= 1ull << k;
+#endif
+            k += lane_get(TB, k);
+        } while (k < 64u);
+        return k;
+    }
+
+    // ---- compaction: the token lanes of up to two halves go to the queue's tail, in order ---------------------
+    // (one crossbar scatter per half; lanes that are not token starts send to lane 63, which is never a queue slot)
+    PZG_FN void queue_append(const LaneVec<uint32_t> &TK0, uint64_t tokens0, uint32_t nt0, const LaneVec<uint32_t> &TK1,
+                             uint64_t tokens1, uint32_t nt1)
+    {
+        LaneVec<uint32_t> DEST, R0, R1;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(DEST, k) = lane_bit(tokens0, k) ? qn + mbcnt_k(tokens0, k) : 63u;
+        PZG_LANES_END
+        lanes_scatter(R0, TK0, DEST);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(DEST, k) = lane_bit(tokens1, k) ? qn + nt0 + mbcnt_k(tokens1, k) : 63u;
+        PZG_LANES_END
+        lanes_scatter(R1, TK1, DEST);
+        PZG_LANES_BEGIN(j)
+            const uint32_t rel = j - qn;  // (wraps for j < qn)
+            PZG_LV(QT, j) = rel < nt0 ? PZG_LV(R0, j) : rel < nt0 + nt1 ? PZG_LV(R1, j) : PZG_LV(QT, j);
+        PZG_LANES_END
+        qn += nt0 + nt1;
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        prof[7] += nt0 + nt1;
+#endif
+    }
+    // the offset of the token that no longer fits when only `room` of the tokens in `tokens` do
+    PZG_FN uint32_t first_beyond(uint64_t tokens, uint32_t room)
+    {
+        LaneVec<bool> FIRST_OUT;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(FIRST_OUT, k) = lane_bit(tokens, k) && mbcnt_k(tokens, k) == room;
+        PZG_LANES_END
+        return ctz64(lanes_ballot(FIRST_OUT));
+    }
+
+    // One 64-bit window (used where fewer than 320 stream bits are left for the 128-bit one).
+    // Precondition: br.window_ok(): at least WINDOW_MIN_BITS real bits follow the cursor, so every token that
     // starts within the next 64 bits (at most 48 bits long) lies inside the stream; qn < QCAP.
     // Returns true when the token now at the cursor must go through token_step_checked().
     PZG_FN bool window_append()
     {
-        // ---- phase A (all lanes) ---------------------------------------------------------------------
         // lane k needs the three dwords that hold stream bits [k, k+96) from the cursor
-        const uint32_t i0 = (uint32_t)(br.pos >> 5), boff = (uint32_t)br.pos & 31u;
-        LaneVec<uint32_t> LO, MID, HI;
-#if PZG_DEVICE_PASS
-        const uint32_t li = i0 - br.chunk0;  // < 64 (slide() keeps the cursor's dword inside `cur`)
-        if (li <= 59u) {                     // all five dwords sit in the current chunk register: three crossbar gathers
-            const uint32_t a = (li + ((boff + lane_id()) >> 5)) << 2;
-            LO.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
-            MID.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
-            HI.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
-        } else
-#endif
+        const uint32_t i0 = br.chunk0 + (br.rp >> 5), boff = br.rp & 31u;
+        LaneVec<uint32_t> TB, TK;
         {
             const uint32_t B0 = br.dword(i0), B1 = br.dword(i0 + 1u), B2 = br.dword(i0 + 2u), B3 = br.dword(i0 + 3u),
                            B4 = br.dword(i0 + 4u);
             PZG_LANES_BEGIN(k)
-                const uint32_t sel = (boff + k) >> 5;
-                PZG_LV(LO, k) = sel == 0u ? B0 : sel == 1u ? B1 : B2;
-                PZG_LV(MID, k) = sel == 0u ? B1 : sel == 1u ? B2 : B3;
-                PZG_LV(HI, k) = sel == 0u ? B2 : sel == 1u ? B3 : B4;
+                const uint32_t sel = (boff + k) >> 5, r = (boff + k) & 31u;
+                const uint32_t lo = sel == 0u ? B0 : sel == 1u ? B1 : B2;
+                const uint32_t mid = sel == 0u ? B1 : sel == 1u ? B2 : B3;
+                const uint32_t hi = sel == 0u ? B2 : sel == 1u ? B3 : B4;
+                decode_at(lo, mid, hi, r, PZG_LV(TB, k), PZG_LV(TK, k));
             PZG_LANES_END
         }
-        LaneVec<uint32_t> TB;  // bits of the token at this offset; 64 = not a plain literal/match: the walk stops here
-        LaneVec<uint32_t> TK;  // the token, in queue format
-        PZG_LANES_BEGIN(k)
-            const uint32_t r = (boff + k) & 31u;
-            const uint32_t lo = PZG_LV(LO, k), mid = PZG_LV(MID, k), hi = PZG_LV(HI, k);
-            decode_at(lo, mid, hi, r, PZG_LV(TB, k), PZG_LV(TK, k));
-        PZG_LANES_END
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
         prof[6] += 1;
 #endif
-        // ---- phase B (scalar): follow the real chain; S = offsets that are token starts ---------------
-        // The only serial part: one v_readlane and four SALU ops per token, no LDS, no lane work.
         uint64_t S = 0;
-        uint32_t kend = 0;
-        do {
-#if PZG_DEVICE_PASS
-            asm("s_bitset1_b64 %0, %1" : "+s"(S) : "s"(kend));  // S |= 1 << kend in one SALU op
-#else
-            S |= 1ull << kend;
-#endif
-            kend += lane_get(TB, kend);
-        } while (kend < 64u);
-        // the chain's last token is the only one that can be a stopper (it ends the walk)
-        LaneVec<bool> ST;
-        PZG_LANES_BEGIN(k)
-            PZG_LV(ST, k) = PZG_LV(TB, k) == 64u;
-        PZG_LANES_END
-        const uint64_t stopbit = S & lanes_ballot(ST);
-        bool stopper = stopbit != 0;
-        uint32_t consumed = stopper ? kend - 64u : kend;
-        uint64_t tokens = S & ~stopbit;
-        // ---- compaction: token lanes go to the queue's tail, in order ---------------------------------
+        const uint32_t kend = walk_half(TB, 0u, S);
+        bool stopper = kend >= 128u;
+        uint32_t consumed = kend;
+        uint64_t tokens = S;
+        if (stopper) {  // the chain's last offset is the stopper: it stays at the cursor
+            consumed = 63u - clz64(S);
+            tokens = S & ~(1ull << consumed);
+        }
         const uint32_t room = QCAP - qn;
         uint32_t nt = popc64(tokens);
         if (nt > room) {  // (a window of very short codes) take what fits, the rest is decoded again
-            LaneVec<bool> FIRST_OUT;
-            PZG_LANES_BEGIN(k)
-                PZG_LV(FIRST_OUT, k) = lane_bit(tokens, k) && mbcnt_k(tokens, k) == room;
-            PZG_LANES_END
-            consumed = ctz64(lanes_ballot(FIRST_OUT));
+            consumed = first_beyond(tokens, room);
             tokens &= (1ull << consumed) - 1ull;
             nt = room;
             stopper = false;
         }
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        prof[7] += nt;
-#endif
-        LaneVec<uint32_t> DEST, RECV;
-        PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = lane_bit(tokens, k) ? qn + mbcnt_k(tokens, k) : 63u;
-        PZG_LANES_END
-        lanes_scatter(RECV, TK, DEST);
-        PZG_LANES_BEGIN(j)
-            PZG_LV(QT, j) = (j >= qn && j < qn + nt) ? PZG_LV(RECV, j) : PZG_LV(QT, j);
-        PZG_LANES_END
-        qn += nt;
+        queue_append(TK, tokens, nt, TK, 0ull, 0u);
         br.drop_short(consumed);
         return stopper;
     }
 
-    // window_append() over 128 bits: lane k decodes at offsets k and k + 64.  The two decodes are
+    // The hot loop's decode step, over 128 bits: lane k decodes at offsets k and k + 64.  The two decodes are
     // independent, so their LDS round trips overlap, and the per-window bookkeeping is paid once.
     // Precondition: br.window2_ok(); qn < QCAP.  Falls back to the first half alone when the queue
-    // cannot take both.
+    // cannot take both.  Returns true when the token now at the cursor must go through token_step_checked().
     PZG_FN bool window_append2()
     {
-        const uint32_t i0 = (uint32_t)(br.pos >> 5), boff = (uint32_t)br.pos & 31u;
         LaneVec<uint32_t> TB0, TK0, TB1, TK1;
 #if PZG_DEVICE_PASS
         {
-            const uint32_t li = i0 - br.chunk0;  // < 64: the window's dwords li .. li + 7 sit in `cur`, or in `cur` and `nxt`
-            const uint32_t q = boff + lane_id();
+            const uint32_t li = br.rp >> 5;  // < 64: the window's dwords li .. li + 7 sit in `cur`, or in `cur` and `nxt`
+            const uint32_t q = (br.rp & 31u) + lane_id();
             const uint32_t d = li + (q >> 5), a = d << 2, r = q & 31u;
             uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
             uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
@@ -1102,89 +1135,56 @@ struct Decoder {
             decode_pair(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
         }
 #else
-        PZG_LANES_BEGIN(k)
-            const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
-            decode_pair(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
-                             PZG_LV(TB0, k), PZG_LV(TK0, k), PZG_LV(TB1, k), PZG_LV(TK1, k));
-        PZG_LANES_END
+        {
+            const uint32_t i0 = br.chunk0 + (br.rp >> 5), boff = br.rp & 31u;
+            PZG_LANES_BEGIN(k)
+                const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
+                decode_pair(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
+                            PZG_LV(TB0, k), PZG_LV(TK0, k), PZG_LV(TB1, k), PZG_LV(TK1, k));
+            PZG_LANES_END
+        }
 #endif
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
         prof[6] += 2;
 #endif
         // ---- the walk: first half, and unless it ended at a stopper, the second -------------------------
-        LaneVec<bool> ST;
         uint64_t S0 = 0, S1 = 0;
-        uint32_t kend = 0;
-        do {
-#if PZG_DEVICE_PASS
-            asm("s_bitset1_b64 %0, %1" : "+s"(S0) : "s"(kend));
-#else
-            S0 |= 1ull << kend;
-#endif
-            kend += lane_get(TB0, kend);
-        } while (kend < 64u);
-        PZG_LANES_BEGIN(k)
-            PZG_LV(ST, k) = PZG_LV(TB0, k) == 64u;
-        PZG_LANES_END
-        const uint64_t stop0 = S0 & lanes_ballot(ST);
-        const uint32_t kend0 = stop0 ? kend - 64u : kend;  // where the first half's chain stops (a stopper) or leaves it
-        uint64_t stop1 = 0;
-        if (!stop0) {
-            kend -= 64u;
-            while (kend < 64u) {
-#if PZG_DEVICE_PASS
-                asm("s_bitset1_b64 %0, %1" : "+s"(S1) : "s"(kend));
-#else
-                S1 |= 1ull << kend;
-#endif
-                kend += lane_get(TB1, kend);
+        const uint32_t k0 = walk_half(TB0, 0u, S0);  // where the chain leaves the first half
+        uint64_t tokens0 = S0, tokens1 = 0;
+        uint32_t consumed;
+        bool stopper = false;
+        if (k0 < 128u) {
+            const uint32_t k1 = walk_half(TB1, k0 - 64u, S1);
+            tokens1 = S1;
+            consumed = k1 + 64u;
+            if (k1 >= 128u) {  // a stopper in the second half: the last offset visited; it stays at the cursor
+                const uint32_t p = 63u - clz64(S1);
+                tokens1 = S1 & ~(1ull << p);
+                consumed = p + 64u;
+                stopper = true;
             }
-            PZG_LANES_BEGIN(k)
-                PZG_LV(ST, k) = PZG_LV(TB1, k) == 64u;
-            PZG_LANES_END
-            stop1 = S1 & lanes_ballot(ST);
-            kend = stop1 ? kend : kend + 64u;  // back to an offset from the cursor (a stopper at k1: k1 + 64 already)
-        } else {
-            kend = kend0;
+        } else {  // a stopper in the first half
+            consumed = 63u - clz64(S0);
+            tokens0 = S0 & ~(1ull << consumed);
+            stopper = true;
         }
-        bool stopper = (stop0 | stop1) != 0;
-        uint32_t consumed = kend;
-        uint64_t tokens0 = S0 & ~stop0, tokens1 = S1 & ~stop1;
         const uint32_t room = QCAP - qn;
         uint32_t nt0 = popc64(tokens0), nt1 = popc64(tokens1);
         if (nt0 + nt1 > room) {  // not both halves: the first alone, the second is decoded again
+            if (tokens1 != 0ull || !stopper) {  // (otherwise consumed / stopper already describe the first half alone)
+                consumed = k0;
+                stopper = false;
+            }
             tokens1 = 0;
             nt1 = 0;
-            consumed = kend0;
-            stopper = stop0 != 0;
             if (nt0 > room) {
-                LaneVec<bool> FIRST_OUT;
-                PZG_LANES_BEGIN(k)
-                    PZG_LV(FIRST_OUT, k) = lane_bit(tokens0, k) && mbcnt_k(tokens0, k) == room;
-                PZG_LANES_END
-                consumed = ctz64(lanes_ballot(FIRST_OUT));
+                consumed = first_beyond(tokens0, room);
                 tokens0 &= (1ull << consumed) - 1ull;
                 nt0 = room;
                 stopper = false;
             }
         }
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        prof[7] += nt0 + nt1;
-#endif
-        LaneVec<uint32_t> DEST, R0, R1;
-        PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = lane_bit(tokens0, k) ? qn + mbcnt_k(tokens0, k) : 63u;
-        PZG_LANES_END
-        lanes_scatter(R0, TK0, DEST);
-        PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = lane_bit(tokens1, k) ? qn + nt0 + mbcnt_k(tokens1, k) : 63u;
-        PZG_LANES_END
-        lanes_scatter(R1, TK1, DEST);
-        PZG_LANES_BEGIN(j)
-            const uint32_t rel = j - qn;  // (wraps for j < qn)
-            PZG_LV(QT, j) = rel < nt0 ? PZG_LV(R0, j) : rel < nt0 + nt1 ? PZG_LV(R1, j) : PZG_LV(QT, j);
-        PZG_LANES_END
-        qn += nt0 + nt1;
+        queue_append(TK0, tokens0, nt0, TK1, tokens1, nt1);
         br.drop_short(consumed);
         return stopper;
     }
@@ -1214,7 +1214,7 @@ struct Decoder {
         PZG_LANES_BEGIN(t)
             const uint32_t tk = PZG_LV(QT, t), lout = (tk >> 16) & 511u, dist = tk & 0xffffu;
             const uint32_t endb = PZG_LV(INCL, t), start = endb - lout;
-            const bool is_match = (tk & LIT_FLAG) == 0u;
+            const bool is_match = (tk & TK_MATCH) != 0u;
             // (bitwise, not short-circuit: one straight-line predicate instead of a lane-dependent branch)
             PZG_LV(STOP, t) = (t < qn) & ((endb > 64u) | (is_match & ((dist < endb) | (dist > hist + start))));
         PZG_LANES_END
@@ -1256,7 +1256,7 @@ struct Decoder {
             PZG_LANES_BEGIN(j)
                 const uint32_t pj = PZG_LV(PJ, j);
                 const uint8_t g = L.ring[(op32 + j - (pj & 0xffffu)) & RMASK];
-                PZG_LV(BV, j) = (pj & LIT_FLAG) ? (pj & 0xffu) : g;
+                PZG_LV(BV, j) = (pj & TK_MATCH) ? g : ((pj >> 8) & 0xffu);
             PZG_LANES_END
             pend_far = 0u;
             PZG_T0(t_d);
@@ -1264,7 +1264,7 @@ struct Decoder {
                 LaneVec<bool> FAR;
                 PZG_LANES_BEGIN(j)
                     const uint32_t pj = PZG_LV(PJ, j);
-                    PZG_LV(FAR, j) = (j < run) & ((pj & LIT_FLAG) == 0u) & ((pj & 0xffffu) - j > RING);
+                    PZG_LV(FAR, j) = (j < run) & ((pj & TK_MATCH) != 0u) & ((pj & 0xffffu) - j > RING);
                 PZG_LANES_END
                 if (lanes_ballot(FAR)) {
                     far_fence();
@@ -1429,7 +1429,7 @@ struct Decoder {
             w = br.peek32();
             const uint32_t e = uni(L.dist_lut[w & ((1u << CL_BITS) - 1u)]);
             if (int st = check_entry(e)) return st;
-            const uint32_t sym = ent_val(e), cn = ent_n(e), ce = ent_e(e);
+            const uint32_t sym = ent_val(e), cn = ent_n(e), ce = ent_cl_extra(e);
             if (br.avail() < (int64_t)(cn + ce)) return fail(ST_TRUNCATED, 0, 0);
             const uint32_t extra = (w >> cn) & ((1u << ce) - 1u);
             br.drop(cn + ce);

@@ -205,9 +205,41 @@ PZG_FN uint32_t mbcnt_k(uint64_t m, uint32_t k)
 }
 
 // (hi:lo) >> r, r in [0,32): v_alignbit_b32
-PZG_FN uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t r)
+// the same on wave-uniform operands: stays a scalar 64-bit shift
+PZG_FN uint32_t funnel_uniform(uint32_t hi, uint32_t lo, uint32_t r)
 {
     return (uint32_t)((((uint64_t)hi << 32) | lo) >> (r & 31u));
+}
+
+PZG_FN uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t r)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_alignbit(hi, lo, r);  // (only r[4:0] counts)
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (r & 31u));
+#endif
+}
+
+// (x >> off[4:0]) & ((1 << width[4:0]) - 1): v_bfe_u32 with both field operands in registers (only their low five bits count)
+PZG_FN uint32_t ubfe(uint32_t x, uint32_t off, uint32_t width)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_ubfe(x, off, width);
+#else
+    off &= 31u;
+    width &= 31u;
+    return (x >> off) & ((1u << width) - 1u);
+#endif
+}
+
+// bytes {a.3, a.2, b.3, b.2}: the high halves of a and b side by side (v_perm_b32)
+PZG_FN uint32_t hi_halves(uint32_t a, uint32_t b)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_perm(a, b, 0x07060302u);
+#else
+    return (a & 0xffff0000u) | (b >> 16);
+#endif
 }
 
 // ---- cross-lane operations on whole LaneVecs (64 lanes) ----------------------------------------
@@ -305,6 +337,7 @@ PZG_FN uint64_t lanes_ballot(const LaneVec<bool> &p)
 }
 
 PZG_FN uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+PZG_FN uint32_t clz64(uint64_t m) { return (uint32_t)__builtin_clzll(m); }
 
 PZG_FN uint32_t bitrev32(uint32_t x)
 {
