@@ -372,13 +372,13 @@ struct Decoder {
     uint32_t lit_sub_used;       // second-level entries taken by the literal/length code (the distance code's follow)
     int32_t status;
     uint32_t detail0, detail1;
-    // The last segment of a window is left pending: its bytes are gathered (LDS) and, for far sources,
-    // requested from HBM/L2, but selected and stored only when the next window has been decoded and
-    // walked, so the far-read latency overlaps that work instead of stalling the wave.
-    uint32_t pend_run;          // bytes of the pending segment (0 = none); they belong at op .. op+pend_run
-    uint32_t pend_far;          // nonzero: pendFV holds far bytes for the lanes flagged in pendBV bit 8
-    LaneVec<uint32_t> pendBV;   // [7:0] byte from the literal / near ring, [8] take the far byte instead
-    LaneVec<uint32_t> pendFV;   // far bytes (valid when pend_far)
+    // A segment's bytes from literals and the near ring are stored at once; bytes whose source is older than
+    // the ring ("far") are requested from HBM/L2 and stored only when the next segment starts (complete_pending),
+    // so the far-read latency overlaps the decode of the next windows instead of stalling the wave.
+    uint64_t pend_m0, pend_m1;  // lanes of the last segment's two 64-byte passes whose byte is still on its way (0 = none)
+    uint32_t pend_pos;          // those bytes belong at ring position pend_pos + 64 * pass + lane
+    LaneVec<uint8_t> pendF0, pendF1;   // the far bytes (valid in the lanes of pend_m0 / pend_m1); bytes, so that nothing
+                                       // (no zero-extension either) touches the loaded registers before complete_pending()
     uint32_t qn;                // tokens waiting in QT (lanes 0..qn-1), see window_append()
     LaneVec<uint32_t> QT;
 #if defined(PZG_PROFILE)
@@ -411,8 +411,9 @@ struct Decoder {
         use_sub = uni(use_sub);
         lit_sub_used = uni(lit_sub_used);
         dist_n = uni(dist_n);
-        pend_run = uni(pend_run);
-        pend_far = uni(pend_far);
+        pend_m0 = uni64(pend_m0);
+        pend_m1 = uni64(pend_m1);
+        pend_pos = uni(pend_pos);
         qn = uni(qn);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
@@ -507,26 +508,29 @@ struct Decoder {
         PZG_ACC(3, tf);
     }
 
-    // store the pending segment (see pend_run) and account for it
+    // store the last segment's far bytes (see pend_m0), then flush if due: from here on every byte below `op` is in the ring
     PZG_FN void complete_pending()
     {
-        if (pend_run == 0u) return;
+        if ((pend_m0 | pend_m1) != 0ull) {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        {
-            PZG_T0(t_w);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PZG_ACC(10, t_w);  // how long the far bytes are waited for
-        }
+            {
+                PZG_T0(t_w);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PZG_ACC(10, t_w);  // how long the far bytes are waited for
+            }
 #endif
-        const uint32_t run = pend_run, op32 = (uint32_t)op;
-        const bool has_far = pend_far != 0u;
-        PZG_LANES_BEGIN(j)
-            const uint32_t bv = PZG_LV(pendBV, j);
-            const uint32_t v = (has_far && (bv & 0x100u)) ? PZG_LV(pendFV, j) : bv;
-            sel_store(j < run, &L.ring[(op32 + j) & RMASK], (uint8_t)v, j);
-        PZG_LANES_END
-        op += run;
-        pend_run = 0u;
+            if (pend_m0 != 0ull) {
+                PZG_LANES_BEGIN(j)
+                    sel_store(lane_bit(pend_m0, j), &L.ring[(pend_pos + j) & RMASK], PZG_LV(pendF0, j), j);
+                PZG_LANES_END
+            }
+            if (pend_m1 != 0ull) {
+                PZG_LANES_BEGIN(j)
+                    sel_store(lane_bit(pend_m1, j), &L.ring[(pend_pos + 64u + j) & RMASK], PZG_LV(pendF1, j), j);
+                PZG_LANES_END
+            }
+            pend_m0 = pend_m1 = 0ull;
+        }
         maybe_flush();
     }
 
@@ -1189,23 +1193,67 @@ struct Decoder {
         return stopper;
     }
 
-    // Place and produce the bytes of the queue's leading tokens.  A segment is at most 64 output
-    // bytes.  Token lanes learn their output offset from a prefix sum of their lengths, drop their
-    // lane id into a marker at that offset, and a prefix maximum tells every output lane which token
-    // it belongs to; one ring gather (+ one far gather) and one ring store follow.  A token ends the
-    // segment (and heads the next one) if it does not fit the 64 lanes or is a match whose source is
-    // not complete before the segment starts (dist < offset + len) or lies before the output
-    // (dist > produced + offset).  A match that heads a segment and still does not fit overlaps its own
-    // output or is longer than a wave: copy_match() takes it.  Precondition: qn != 0.
+    // Place and produce the bytes of the queue's leading tokens.  A segment is at most SEG = 128 output bytes, produced
+    // in two passes of 64 (lane j: bytes j and 64 + j); the work per token is paid once for both.
+    // Token lanes learn their output offset from a prefix sum of their lengths and announce themselves at that offset
+    // (one crossbar scatter per pass); counting the announcements up to its own position tells every output lane which
+    // token it belongs to; one ring gather (+ one far gather) and one ring store per pass follow.  A token ends the
+    // segment (and heads the next one) if it does not fit the 128 bytes or is a match whose source is not complete
+    // before the segment starts (dist < offset + len) or lies before the output (dist > produced + offset).  A match
+    // that heads a segment and still does not fit overlaps its own output or is longer than the segment: copy_match()
+    // takes it.  Precondition: qn != 0.
+    static constexpr uint32_t SEG = 128u;
+
+    // one pass of a segment, the gather: VAL = the byte of output offset o = 64 * pass + lane (from its literal token or
+    // the near ring), FARM = the lanes whose source is older than the ring; DIST = their tokens' distances.
+    PZG_FN uint64_t segment_gather(const LaneVec<uint32_t> &TOK, uint32_t o0, uint32_t run, uint32_t op32, LaneVec<uint32_t> &VAL,
+                                   LaneVec<uint32_t> &DIST)
+    {
+        LaneVec<uint32_t> PJ;
+        lanes_gather(PJ, QT, TOK);
+        LaneVec<bool> FAR;
+        PZG_LANES_BEGIN(j)
+            const uint32_t pj = PZG_LV(PJ, j), o = o0 + j, dist = pj & 0xffffu;
+            const bool is_match = (int32_t)pj < 0;
+            const uint8_t g = L.ring[(op32 + o - dist) & RMASK];
+            PZG_LV(VAL, j) = is_match ? (uint32_t)g : ((pj >> 8) & 0xffu);
+            PZG_LV(DIST, j) = dist;
+            PZG_LV(FAR, j) = HYBRID & (o < run) & is_match & (dist - o > RING);
+        PZG_LANES_END
+        return HYBRID ? lanes_ballot(FAR) : 0ull;
+    }
+    // ... the stores: at once for the lanes that have their byte; the far lanes' bytes are requested and left pending.
+    // The far request is ONE unconditional load per pass, straight-line (a load inside a branch makes the compiler merge
+    // its result with the old register -- a copy that waits for the load on the spot): base + 32-bit lane offset, lanes
+    // with no far source re-read a byte that is there anyway.
+    PZG_FN void segment_store(uint32_t o0, uint32_t run, uint32_t op32, const LaneVec<uint32_t> &VAL, const LaneVec<uint32_t> &DIST,
+                              uint64_t farm, const uint8_t *far_base, bool far_ok, LaneVec<uint8_t> &pendF)
+    {
+        PZG_LANES_BEGIN(j)
+            const uint32_t o = o0 + j;
+            sel_store((o < run) & !lane_bit(farm, j), &L.ring[(op32 + o) & RMASK], (uint8_t)PZG_LV(VAL, j), j);
+        PZG_LANES_END
+        if (HYBRID) {  // sources older than the ring: the stream's own flushed output
+            PZG_LANES_BEGIN(j)
+                const uint32_t off = (far_ok & lane_bit(farm, j)) ? 32768u + (o0 + j) - PZG_LV(DIST, j) : 32768u;
+#if PZG_DEVICE_PASS
+                PZG_LV(pendF, j) = __builtin_nontemporal_load(far_base + off);
+#else
+                PZG_LV(pendF, j) = off != 32768u ? far_base[off] : (uint8_t)0;
+#endif
+            PZG_LANES_END
+        }
+    }
+
     PZG_FN int emit_segment()
     {
         PZG_T0(t_a);
-        complete_pending();  // the previous segment's bytes must be in the ring (and in `op`) from here on
+        complete_pending();  // the previous segment's bytes must all be in the ring from here on
         PZG_ACCW(8, t_a);
         PZG_T0(t_b);
         const uint32_t hist = (op >> 20) ? 0x100000u : (uint32_t)op;  // dist <= 32768: a clamp is enough (scalar shift + test)
         const uint32_t op32 = (uint32_t)op;
-        LaneVec<uint32_t> INCL;
+        LaneVec<uint32_t> INCL, START;
         LaneVec<bool> STOP;
         PZG_LANES_BEGIN(t)
             PZG_LV(INCL, t) = t < qn ? ((PZG_LV(QT, t) >> 16) & 511u) : 0u;
@@ -1214,14 +1262,14 @@ struct Decoder {
         PZG_LANES_BEGIN(t)
             const uint32_t tk = PZG_LV(QT, t), lout = (tk >> 16) & 511u, dist = tk & 0xffffu;
             const uint32_t endb = PZG_LV(INCL, t), start = endb - lout;
-            const bool is_match = (tk & TK_MATCH) != 0u;
+            const bool is_match = (int32_t)tk < 0;
+            PZG_LV(START, t) = start;
             // (bitwise, not short-circuit: one straight-line predicate instead of a lane-dependent branch)
-            PZG_LV(STOP, t) = (t < qn) & ((endb > 64u) | (is_match & ((dist < endb) | (dist > hist + start))));
+            PZG_LV(STOP, t) = (t < qn) & ((endb > SEG) | (is_match & ((dist < endb) | (dist > hist + start))));
         PZG_LANES_END
         const uint64_t stopmask = lanes_ballot(STOP);
         uint32_t v = stopmask ? ctz64(stopmask) : qn;  // tokens of this segment
         PZG_ACCW(9, t_b);
-        PZG_T0(t_c);
         if (v == 0u) {
             const uint32_t tk = lane_get(QT, 0u), dist = tk & 0xffffu, len = (tk >> 16) & 511u;
             if ((uint64_t)dist > op) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
@@ -1235,51 +1283,54 @@ struct Decoder {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             prof[13] += 1;
 #endif
+            PZG_T0(t_d);
             const uint32_t run = lane_get(INCL, v - 1u);
-            // Which token does output byte j belong to?  Token t announces itself at lane START[t] (one
-            // crossbar scatter); the tokens sit in the queue in output order, so byte j belongs to token
-            // (number of announcements at lanes <= j) - 1.  Lanes that send nothing real repeat token 0's
-            // announcement at lane 0, so colliding writes all carry the same value.
-            LaneVec<uint32_t> TOK, PJ, ONE, DEST, MARK;
+            // Which token does output byte o belong to?  Token t announces itself at lane START[t] of its pass (one
+            // crossbar scatter); the tokens sit in the queue in output order, so byte o belongs to token
+            // (number of announcements at offsets <= o) - 1.  Lanes that send nothing real repeat an announcement that
+            // is made anyway -- token 0's at lane 0 in the first pass, the last token's in the second -- so colliding
+            // writes all carry the same value.
+            LaneVec<uint32_t> ONE, DEST, MARK, TOK, VAL0, VAL1, DIST0, DIST1;
             PZG_LANES_BEGIN(t)
-                const uint32_t lout = (PZG_LV(QT, t) >> 16) & 511u;
-                PZG_LV(DEST, t) = t < v ? PZG_LV(INCL, t) - lout : 0u;
+                PZG_LV(DEST, t) = ((t < v) & (PZG_LV(START, t) < 64u)) ? PZG_LV(START, t) : 0u;
                 PZG_LV(ONE, t) = 1u;
             PZG_LANES_END
             lanes_scatter(MARK, ONE, DEST);
-            const uint64_t starts = lanes_ballot(MARK);
+            const uint64_t starts0 = lanes_ballot(MARK);  // (bit 0 is always set)
             PZG_LANES_BEGIN(j)
-                PZG_LV(TOK, j) = (mbcnt_k(starts, j) - (lane_bit(starts, j) ? 0u : 1u)) & 63u;
+                PZG_LV(TOK, j) = mbcnt_k(starts0 >> 1, j);  // announcements at offsets 1 .. j
             PZG_LANES_END
-            lanes_gather(PJ, QT, TOK);
-            LaneVec<uint32_t> BV;
-            PZG_LANES_BEGIN(j)
-                const uint32_t pj = PZG_LV(PJ, j);
-                const uint8_t g = L.ring[(op32 + j - (pj & 0xffffu)) & RMASK];
-                PZG_LV(BV, j) = (pj & TK_MATCH) ? g : ((pj >> 8) & 0xffu);
-            PZG_LANES_END
-            pend_far = 0u;
-            PZG_T0(t_d);
-            if (HYBRID) {  // sources older than the ring: the stream's own flushed output
-                LaneVec<bool> FAR;
-                PZG_LANES_BEGIN(j)
-                    const uint32_t pj = PZG_LV(PJ, j);
-                    PZG_LV(FAR, j) = (j < run) & ((pj & TK_MATCH) != 0u) & ((pj & 0xffffu) - j > RING);
-                PZG_LANES_END
-                if (lanes_ballot(FAR)) {
-                    far_fence();
-                    pend_far = 1u;
-                    PZG_LANES_BEGIN(j)
-                        const bool far = PZG_LV(FAR, j);
-                        PZG_LV(pendFV, j) = fetch_far(far, (PZG_LV(PJ, j) & 0xffffu) - j);  // issued now, waited for in complete_pending()
-                        PZG_LV(BV, j) = (PZG_LV(BV, j) & 0xffu) | (far ? 0x100u : 0u);
+            const uint64_t farm0 = segment_gather(TOK, 0u, run, op32, VAL0, DIST0);
+            uint64_t farm1 = 0ull;
+            if (run > 64u) {
+                const uint32_t start_last = lane_get(START, v - 1u);
+                uint64_t starts1 = 0ull;
+                if (start_last >= 64u) {  // (otherwise the last token covers the whole second pass)
+                    PZG_LANES_BEGIN(t)
+                        PZG_LV(DEST, t) = (((t < v) & (PZG_LV(START, t) >= 64u)) ? PZG_LV(START, t) : start_last) - 64u;
                     PZG_LANES_END
+                    lanes_scatter(MARK, ONE, DEST);
+                    starts1 = lanes_ballot(MARK);
                 }
+                // token of offset 64: the last one announced in the first pass, or the one announced at 64 itself
+                const uint32_t base1 = popc64(starts0) - 1u + ((uint32_t)starts1 & 1u);
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(TOK, j) = base1 + mbcnt_k(starts1 >> 1, j);
+                PZG_LANES_END
+                farm1 = segment_gather(TOK, 64u, run, op32, VAL1, DIST1);
             }
-            PZG_LANES_BEGIN(j)
-                PZG_LV(pendBV, j) = PZG_LV(BV, j);
-            PZG_LANES_END
-            pend_run = run;  // stored by complete_pending(): next segment, or on the way out
+            // both gathers precede the stores: the first pass' bytes replace ring bytes the second may still read
+            // Far sources lie below op, so inside the capacity while op is; a stream that has outgrown its capacity is
+            // redone by the 32 KiB-ring kernel anyway (its far bytes were never stored): it reads its input instead.
+            const bool far_ok = op < cap;
+            const uint8_t *far_base = far_ok ? out + (op - 32768u) : in - 32768;
+            if (HYBRID && (farm0 | farm1) != 0ull) far_fence();
+            segment_store(0u, run, op32, VAL0, DIST0, farm0, far_base, far_ok, pendF0);
+            if (run > 64u) segment_store(64u, run, op32, VAL1, DIST1, farm1, far_base, far_ok, pendF1);
+            pend_m0 = farm0;
+            pend_m1 = farm1;
+            pend_pos = op32;
+            op += run;
             PZG_ACC(11, t_d);
         }
         // the queue moves up by v tokens
@@ -1484,7 +1535,8 @@ struct Decoder {
         lit_n = dist_n = 0;
         use_sub = 0;
         lit_sub_used = 0;
-        pend_run = pend_far = 0;
+        pend_m0 = pend_m1 = 0;
+        pend_pos = 0;
         qn = 0;
         status = ST_OK;
         detail0 = detail1 = 0;
