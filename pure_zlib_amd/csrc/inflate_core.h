@@ -1013,20 +1013,33 @@ struct Decoder {
     }
 
     // ---- phase B (scalar): follow the real chain through one 64-offset half --------------------------------
-    // S collects the offsets visited from k on (the token starts); returns where the chain leaves the half: an offset
-    // >= 64, and >= 128 exactly when it ran into a stopper (a stopper's tb has bit 7 set; a token's is at most 48).
-    // The only serial part of the decode: one v_readlane, three SALU ops and a branch per token.
+    // S collects the offsets visited from k on (the token starts).  Returns where the chain leaves the half MINUS 64:
+    // below 64 it is the offset at which the next half is entered; 64 or more means the chain ran into a stopper (a
+    // stopper's tb has bit 7 set; a token's is at most 48).
+    // The only serial part of the decode, and the scalar unit is what the kernel runs out of first: two SALU
+    // instructions, one v_readlane and one branch per token.  The offset is carried biased by -64 (mod 2^32), so the add
+    // that advances it sets SCC exactly when the chain leaves the half -- no compare; s_bitset1 and v_readlane use the
+    // low six bits of their index, which the bias leaves alone.
     PZG_FN uint32_t walk_half(const LaneVec<uint32_t> &TB, uint32_t k, uint64_t &S)
     {
-        do {
 #if PZG_DEVICE_PASS
-            asm("s_bitset1_b64 %0, %1" : "+s"(S) : "s"(k));  // S |= 1 << k in one SALU op
+        uint32_t kb = k - 64u, t;
+        asm("1:\n\t"
+            "s_bitset1_b64 %0, %1\n\t"
+            "v_readlane_b32 %2, %3, %1\n\t"
+            "s_add_u32 %1, %1, %2\n\t"
+            "s_cbranch_scc0 1b"
+            : "+s"(S), "+s"(kb), "=&s"(t)
+            : "v"(TB.v)
+            : "scc");
+        return kb;
 #else
+        do {
             S |= 1ull << k;
-#endif
             k += lane_get(TB, k);
         } while (k < 64u);
-        return k;
+        return k - 64u;
+#endif
     }
 
     // ---- compaction: the token lanes of up to two halves go to the queue's tail, in order ---------------------
@@ -1036,11 +1049,11 @@ struct Decoder {
     {
         LaneVec<uint32_t> DEST, R0, R1;
         PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = lane_bit(tokens0, k) ? qn + mbcnt_k(tokens0, k) : 63u;
+            PZG_LV(DEST, k) = mask_select(tokens0, k, qn + mbcnt_k(tokens0, k), 63u);
         PZG_LANES_END
         lanes_scatter(R0, TK0, DEST);
         PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = lane_bit(tokens1, k) ? qn + nt0 + mbcnt_k(tokens1, k) : 63u;
+            PZG_LV(DEST, k) = mask_select(tokens1, k, qn + nt0 + mbcnt_k(tokens1, k), 63u);
         PZG_LANES_END
         lanes_scatter(R1, TK1, DEST);
         PZG_LANES_BEGIN(j)
@@ -1086,9 +1099,9 @@ struct Decoder {
         prof[6] += 1;
 #endif
         uint64_t S = 0;
-        const uint32_t kend = walk_half(TB, 0u, S);
-        bool stopper = kend >= 128u;
-        uint32_t consumed = kend;
+        const uint32_t kend = walk_half(TB, 0u, S);  // (minus 64)
+        bool stopper = kend >= 64u;
+        uint32_t consumed = kend + 64u;
         uint64_t tokens = S;
         if (stopper) {  // the chain's last offset is the stopper: it stays at the cursor
             consumed = 63u - clz64(S);
@@ -1152,31 +1165,47 @@ struct Decoder {
         prof[6] += 2;
 #endif
         // ---- the walk: first half, and unless it ended at a stopper, the second -------------------------
+        // The common case is written straight through (no flags to merge): both halves walked, no stopper, the queue
+        // takes every token.  Anything else goes through window2_rare().
         uint64_t S0 = 0, S1 = 0;
-        const uint32_t k0 = walk_half(TB0, 0u, S0);  // where the chain leaves the first half
-        uint64_t tokens0 = S0, tokens1 = 0;
-        uint32_t consumed;
-        bool stopper = false;
-        if (k0 < 128u) {
-            const uint32_t k1 = walk_half(TB1, k0 - 64u, S1);
-            tokens1 = S1;
-            consumed = k1 + 64u;
-            if (k1 >= 128u) {  // a stopper in the second half: the last offset visited; it stays at the cursor
-                const uint32_t p = 63u - clz64(S1);
-                tokens1 = S1 & ~(1ull << p);
-                consumed = p + 64u;
-                stopper = true;
+        const uint32_t k0 = walk_half(TB0, 0u, S0);  // where the chain enters the second half (64 or more: a stopper)
+        if (__builtin_expect(k0 < 64u, 1)) {
+            const uint32_t k1 = walk_half(TB1, k0, S1);
+            if (__builtin_expect(k1 < 64u, 1)) {
+                const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
+                if (__builtin_expect(qn + nt0 + nt1 <= QCAP, 1)) {
+                    queue_append(TK0, S0, nt0, TK1, S1, nt1);
+                    br.drop_short(k1 + 128u);
+                    return false;
+                }
             }
-        } else {  // a stopper in the first half
+            return window2_rare(TK0, TK1, S0, S1, k0, k1);
+        }
+        return window2_rare(TK0, TK1, S0, 0ull, k0, 0u);
+    }
+
+    // window_append2() when a half ended at a stopper or the queue cannot take every token
+    PZG_FN bool window2_rare(const LaneVec<uint32_t> &TK0, const LaneVec<uint32_t> &TK1, uint64_t S0, uint64_t S1, uint32_t k0, uint32_t k1)
+    {
+        uint64_t tokens0 = S0, tokens1 = S1;
+        uint32_t consumed = k1 + 128u;
+        bool stopper = false;
+        if (k0 >= 64u) {  // a stopper in the first half: the last offset visited; it stays at the cursor
             consumed = 63u - clz64(S0);
             tokens0 = S0 & ~(1ull << consumed);
+            tokens1 = 0;
+            stopper = true;
+        } else if (k1 >= 64u) {  // ... in the second half
+            const uint32_t p = 63u - clz64(S1);
+            tokens1 = S1 & ~(1ull << p);
+            consumed = p + 64u;
             stopper = true;
         }
         const uint32_t room = QCAP - qn;
         uint32_t nt0 = popc64(tokens0), nt1 = popc64(tokens1);
         if (nt0 + nt1 > room) {  // not both halves: the first alone, the second is decoded again
             if (tokens1 != 0ull || !stopper) {  // (otherwise consumed / stopper already describe the first half alone)
-                consumed = k0;
+                consumed = k0 + 64u;
                 stopper = false;
             }
             tokens1 = 0;
@@ -1345,13 +1374,24 @@ struct Decoder {
 
     PZG_FN int token_loop()
     {
-        bool stopper = false;  // the token at the cursor is one for token_step_checked()
         for (;;) {
+            // fill the queue: 128-bit windows while at least 320 stream bits are ahead, then 64-bit ones; a window
+            // returns true when the token at the cursor is one for token_step_checked()
             PZG_T0(tw);
-            while (!stopper && qn < QHIGH)
-                stopper = br.window2_ok() ? window_append2() : !br.window_ok() || window_append();
+            bool checked = false;
+            while (qn < QHIGH) {
+                if (__builtin_expect(br.window2_ok(), 1)) {
+                    if (__builtin_expect(window_append2(), 0)) {
+                        checked = true;
+                        break;
+                    }
+                } else if (!br.window_ok() || window_append()) {
+                    checked = true;
+                    break;
+                }
+            }
             PZG_ACC(4, tw);
-            if (qn >= QHIGH) {
+            if (!checked) {
                 PZG_T0(te);
                 const int se = emit_segment();
                 PZG_ACC(12, te);
@@ -1364,7 +1404,6 @@ struct Decoder {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             prof[15] += 1;
 #endif
-            stopper = false;
             if (st == ST_OK) continue;
             // end of block or error: first everything that precedes it in the stream (an error there wins)
             while (qn != 0u) {

@@ -193,6 +193,20 @@ PZG_FN bool lane_bit(uint64_t m, uint32_t k)
 #endif
 }
 
+// bit k of the wave-uniform mask m ? a : b, as ONE v_cndmask with the mask as its scalar operand (left to itself the
+// compiler narrows EXEC around the computation of `a` instead: two scalar instructions where the scalar unit is scarce)
+PZG_FN uint32_t mask_select(uint64_t m, uint32_t k, uint32_t a, uint32_t b)
+{
+#if PZG_DEVICE_PASS
+    (void)k;
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+#else
+    return ((m >> k) & 1ull) ? a : b;
+#endif
+}
+
 // number of set bits of m below lane k
 PZG_FN uint32_t mbcnt_k(uint64_t m, uint32_t k)
 {
