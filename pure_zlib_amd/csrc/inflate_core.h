@@ -259,10 +259,11 @@ struct BitReader {
     //   128-bit window  dword index of the cursor + 3 < win_end   (10 whole dwords follow)
     PZG_FN void set_limits()
     {
-        int64_t d = (int64_t)win_end - (int64_t)chunk0;
-        d = d > 4096 ? 4096 : d < 0 ? 0 : d;  // (rp stays below 2048 + one window: anything past that is "yes")
-        rp_ok1 = (int32_t)d * 32;
-        rp_ok2 = ((int32_t)d - 3) * 32;
+        // (32-bit arithmetic only: a 64-bit compare would be a vector instruction and leave the limits in vector registers)
+        uint32_t d = win_end >= chunk0 ? win_end - chunk0 : 0u;
+        d = d > 4096u ? 4096u : d;  // (rp stays below 2048 + one window: anything past that is "yes")
+        rp_ok1 = (int32_t)uni(d * 32u);  // (pinned to scalar registers: the hot loop compares against them once per window)
+        rp_ok2 = (int32_t)uni(d * 32u - 96u);
     }
 
     PZG_FN void start(const uint8_t *in, uint64_t in_len, uint64_t byte_pos)
@@ -322,9 +323,9 @@ struct BitReader {
 
     PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos(); }
     // cheap sufficient test for avail() >= 192 (7 whole dwords follow the cursor's dword index)
-    PZG_FN bool window_ok() const { return (int32_t)rp < rp_ok1; }
+    PZG_FN bool window_ok() const { return (int32_t)rp < (int32_t)uni((uint32_t)rp_ok1); }
     // same for a 128-bit window (10 whole dwords follow)
-    PZG_FN bool window2_ok() const { return (int32_t)rp < rp_ok2; }
+    PZG_FN bool window2_ok() const { return (int32_t)rp < (int32_t)uni((uint32_t)rp_ok2); }  // (uni: keeps the compare scalar)
 
     // the next 32 bits (bits past the stream end read as whatever follows; callers check avail())
     PZG_FN uint32_t peek32() const
@@ -1372,24 +1373,25 @@ struct Decoder {
         return ST_OK;
     }
 
+    // Fill the queue: 128-bit windows while at least 320 stream bits are ahead, then 64-bit ones.  Returns true when
+    // the token at the cursor is one for token_step_checked() (a window said so, or too few bits are left for one).
+    PZG_FN bool fill_queue()
+    {
+        do {
+            if (__builtin_expect(br.window2_ok(), 1)) {
+                if (__builtin_expect(window_append2(), 0)) return true;
+            } else {
+                if (!br.window_ok() || window_append()) return true;
+            }
+        } while (qn < QHIGH);
+        return false;
+    }
+
     PZG_FN int token_loop()
     {
         for (;;) {
-            // fill the queue: 128-bit windows while at least 320 stream bits are ahead, then 64-bit ones; a window
-            // returns true when the token at the cursor is one for token_step_checked()
             PZG_T0(tw);
-            bool checked = false;
-            while (qn < QHIGH) {
-                if (__builtin_expect(br.window2_ok(), 1)) {
-                    if (__builtin_expect(window_append2(), 0)) {
-                        checked = true;
-                        break;
-                    }
-                } else if (!br.window_ok() || window_append()) {
-                    checked = true;
-                    break;
-                }
-            }
+            const bool checked = qn < QHIGH && fill_queue();
             PZG_ACC(4, tw);
             if (!checked) {
                 PZG_T0(te);
@@ -1399,7 +1401,7 @@ struct Decoder {
                 continue;
             }
             PZG_T0(tc);
-            int st = token_step_checked();
+            const int st = token_step_checked();
             PZG_ACC(5, tc);
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             prof[15] += 1;

@@ -35,11 +35,24 @@ constexpr uint32_t waves_per_cu()
     return by_lds < by_vgpr ? by_lds : by_vgpr;
 }
 
+// The launch arguments are NOT kept in scalar registers across a stream: the decoder's own wave-uniform state
+// already fills the scalar register file (what does not fit is spilled into vector-register lanes, and uniform
+// values start living in vector registers inside the hot loop).  They are read from the kernel-argument segment
+// when a stream starts and again when its results are stored; the empty asm makes the pointer opaque at those two
+// points so that the loads are not hoisted out of the stream loop.
+typedef const InflateArgs __attribute__((address_space(4))) *LaunchArgs;  // (constant address space: scalar loads)
+__device__ __forceinline__ LaunchArgs launch_args()
+{
+    LaunchArgs kp = (LaunchArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp)::"memory");
+    return kp;
+}
+
 template <int RING_BITS, bool FIXUP, bool GZIP = false>
-__global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(InflateArgs a)
+__global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(InflateArgs)
 {
     __shared__ WaveLds<RING_BITS> lds;
-    if (FIXUP && __builtin_nontemporal_load(a.counter + 1) == 0u) return;  // nothing was handed back
+    if (FIXUP && __builtin_nontemporal_load(launch_args()->counter + 1) == 0u) return;  // nothing was handed back
     if (threadIdx.x == 0) lds.fixed_ready = 0u;  // LDS is not zeroed at launch
     __syncthreads();
     // Persistent stream-waves: the grid is sized to the residency of the chip and every wave pulls
@@ -48,37 +61,41 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(
     // more in dispatch than the small streams take to decode).
     for (;;) {
         uint32_t i = 0;
-        if (threadIdx.x == 0) i = atomicAdd(a.counter, 1u);
-        i = uni(i);
-        if (i >= a.n) break;
-#if !defined(PZG_PROFILE)
-        if (a.order) i = a.order[i];
-#endif
-        // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
-        if (FIXUP && a.status[i] != ST_RETRY_FULL_RING) continue;
-        Decoder<RING_BITS, GZIP> dec(lds);
         StreamResult r;
-        dec.run(a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i], &r);
-        if (threadIdx.x == 0) {
-            a.status[i] = r.status;
-            if (!FIXUP && r.status == ST_RETRY_FULL_RING) atomicAdd(a.counter + 1, 1u);
-            a.out_len[i] = r.out_len;
-            const bool gz_ok = GZIP && r.status == ST_OK;  // then the detail words carry the trailer's CRC-32 and ISIZE
-            if (a.detail) {
-                a.detail[2 * (size_t)i] = gz_ok ? 0u : r.detail0;
-                a.detail[2 * (size_t)i + 1] = gz_ok ? 0u : r.detail1;
-            }
-            if (a.in_used) a.in_used[i] = r.in_used;
-            if (a.adler) a.adler[i] = GZIP ? 0u : r.adler;  // gzip: crc32_verify_kernel fills in the CRC-32
-            if (GZIP) {
-                a.gz_expect[2 * (size_t)i] = r.detail0;
-                a.gz_expect[2 * (size_t)i + 1] = r.detail1;
-            }
+        {
+            LaunchArgs a = launch_args();
+            if (threadIdx.x == 0) i = atomicAdd(a->counter, 1u);
+            i = uni(i);
+            if (i >= a->n) break;
+#if !defined(PZG_PROFILE)
+            if (a->order) i = a->order[i];
+#endif
+            // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
+            if (FIXUP && a->status[i] != ST_RETRY_FULL_RING) continue;
+            Decoder<RING_BITS, GZIP> dec(lds);
+            dec.run(a->in_base + a->in_off[i], a->in_len[i], a->out_base + a->out_off[i], a->out_cap[i], &r);
 #if defined(PZG_PROFILE)
             // diagnostic build: the 16 phase counters of stream i go to prof_out[16*i ..]
-            if (a.prof_out)
-                for (int q = 0; q < 16; ++q) a.prof_out[16 * (size_t)i + q] = dec.prof[q];
+            if (threadIdx.x == 0 && a->prof_out)
+                for (int q = 0; q < 16; ++q) a->prof_out[16 * (size_t)i + q] = dec.prof[q];
 #endif
+        }
+        LaunchArgs a = launch_args();
+        if (threadIdx.x == 0) {
+            a->status[i] = r.status;
+            if (!FIXUP && r.status == ST_RETRY_FULL_RING) atomicAdd(a->counter + 1, 1u);
+            a->out_len[i] = r.out_len;
+            const bool gz_ok = GZIP && r.status == ST_OK;  // then the detail words carry the trailer's CRC-32 and ISIZE
+            if (a->detail) {
+                a->detail[2 * (size_t)i] = gz_ok ? 0u : r.detail0;
+                a->detail[2 * (size_t)i + 1] = gz_ok ? 0u : r.detail1;
+            }
+            if (a->in_used) a->in_used[i] = r.in_used;
+            if (a->adler) a->adler[i] = GZIP ? 0u : r.adler;  // gzip: crc32_verify_kernel fills in the CRC-32
+            if (GZIP) {
+                a->gz_expect[2 * (size_t)i] = r.detail0;
+                a->gz_expect[2 * (size_t)i + 1] = r.detail1;
+            }
         }
         __syncthreads();
     }
