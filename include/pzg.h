@@ -15,8 +15,9 @@
  * HIP kernels on a gfx950 device and fails loudly (negative return code) when no
  * device is usable.
  *
- * Threading: a pzg_ctx serialises its own calls internally (one HIP stream per
- * context); distinct contexts may be used from distinct threads concurrently.
+ * Threading: a pzg_ctx may be shared by threads.  Host-pointer calls take one of the context's
+ * independent pipelines (HIP streams + staging) each and overlap; device-pointer launches are
+ * enqueued on the context's stream in call order, each with its own work counter.
  * Ownership: the caller allocates and owns every buffer; the library retains no
  * caller pointer past return (except with PZG_ASYNC, until pzg_sync()).
  * No exception crosses the boundary.
@@ -77,12 +78,21 @@ extern "C" {
 #define PZG_ASYNC        2u  /* enqueue only (requires PZG_DEVICE_PTRS); caller calls pzg_sync() */
 #define PZG_GZIP         4u  /* EXTENSION (the reference has no gzip: README.md:42-50 TODO): every stream is
                               * one RFC 1952 member (gzip header, deflate, CRC-32 + ISIZE); adler[] then holds the CRC-32 */
+#define PZG_LPT_ORDER    8u  /* device-pointer batches of mixed sizes: launch the longest streams (largest out_cap[]) first; the
+                              * permutation is built on the device.  Host-pointer batches are always launched that way. */
 
 typedef struct pzg_ctx pzg_ctx;
 
 /* Create a context on HIP device `device` (0-based).  One HIP stream + grow-only device
  * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device. */
 int  pzg_init(int device, pzg_ctx **out);
+/* decompressMany over SEVERAL devices of one node (API of Zlib.hs:32-35, batched): bit d of `device_mask`
+ * selects HIP device d, 0 selects every visible device.  One call of pzg_decompress_many() with HOST pointers then
+ * partitions the streams over the devices (longest-processing-time-first by capacity), one host thread, HIP stream set
+ * and staging arenas per device, and every result lands in the caller's own out_off[] / status[] slots: the streams
+ * are independent, so nothing crosses between devices (no collective).  PZG_DEVICE_PTRS calls need a one-device context. */
+int  pzg_init_mask(uint32_t device_mask, pzg_ctx **out);
+int  pzg_device_count(pzg_ctx *ctx);  /* devices (shards) of the context */
 void pzg_shutdown(pzg_ctx *ctx);
 
 /* Make the context launch on an existing HIP stream (e.g. a framework's current stream) instead of
@@ -138,6 +148,11 @@ int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len,
  * reduction.  `init` is a finalized Adler value (1 for a fresh checksum). */
 int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init,
                 uint32_t *out, uint32_t flags);
+
+/* The batched form (BASELINE config 2, 262,144 x 64 KiB): out[i] = Adler-32 of base[off[i] .. off[i]+len[i]), one wave per
+ * buffer.  Device memory only (PZG_DEVICE_PTRS). */
+int pzg_adler32_many(pzg_ctx *ctx, const uint8_t *base, const uint64_t *off, const uint64_t *len,
+                     uint32_t *out, uint32_t n, uint32_t flags);
 
 /* Exact `show` text of the DecompressionError the reference returns for (status, detail) on
  * this stream (host memory; needed only for PZG_E_HUFF_BUILD, whose message depends on the

@@ -33,12 +33,13 @@ E_GZIP_ISIZE = 19
 DEVICE_PTRS = 1
 ASYNC = 2
 GZIP = 4  # extension: streams are RFC 1952 members; adler[] holds the CRC-32
+LPT_ORDER = 8  # device-pointer batches: launch the longest streams first
 OPT_RING_BITS = 1
 DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares
 SYMBOLS = [
-    "pzg_init", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
+    "pzg_init", "pzg_init_mask", "pzg_device_count", "pzg_adler32_many", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
     "pzg_adler32", "pzg_error_message", "pzg_last_kernel_ms", "pzg_strerror", "pzg_last_error", "pzg_version",
 ]
 
@@ -63,6 +64,12 @@ def lib():
     vp, u64p, i32p, u32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.pzg_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.pzg_init.restype = C.c_int
+    L.pzg_init_mask.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
+    L.pzg_init_mask.restype = C.c_int
+    L.pzg_device_count.argtypes = [C.c_void_p]
+    L.pzg_device_count.restype = C.c_int
+    L.pzg_adler32_many.argtypes = [C.c_void_p, vp, u64p, u64p, u32p, C.c_uint32, C.c_uint32]
+    L.pzg_adler32_many.restype = C.c_int
     L.pzg_shutdown.argtypes = [C.c_void_p]
     L.pzg_shutdown.restype = None
     L.pzg_set_stream.argtypes = [C.c_void_p, C.c_void_p]

@@ -2,18 +2,34 @@
 //
 // No CPU decode path exists in this library.  Every compute entry point launches the gfx950
 // kernels of pzg_kernels.hip; when HIP has no usable device the calls fail with PZG_RC_NO_DEVICE.
+//
+// Structure:
+//   pzg_ctx      one or more device shards (pzg_init: one device; pzg_init_mask: every device of the mask)
+//   Shard        one device: the launch stream of the device-pointer path + a few Lanes
+//   Lane         one independent host-buffer pipeline: three HIP streams (H2D, kernels, D2H), double-buffered device
+//                arenas and pinned staging slots.  A host-pointer call takes a free lane of its shard, so calls from
+//                several threads overlap instead of queueing behind one mutex.
+// Host-pointer batches are packed (no gaps travel over PCIe), launched longest stream first, and flow through the
+// lane in index ranges: pack + H2D of range c+1, the kernel on range c and D2H + copy-out of range c-1 overlap, and
+// the two PCIe directions run on their own streams.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <new>
+#include <numeric>
+#include <string>
 #include <thread>
 #include <vector>
-#include <new>
-#include <string>
 
 #include "../../include/pzg.h"
 #include "pzg_launch.h"
@@ -24,28 +40,75 @@ struct Arena {
     void *p = nullptr;
     size_t cap = 0;
 };
+struct Pinned {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+};
 
 constexpr uint32_t ADLER_MAX_WAVES = 8192;  // 256 CUs x 32 waves
+constexpr int LANES_PER_SHARD = 4;
+constexpr int COUNTER_SLOTS = 16;           // device-pointer launches in flight on one shard, each with its own counter
+constexpr size_t RANGE_MAX_OUT = 256ull << 20;  // a range's packed output stays below this (bounds the pinned staging)
+
+// a small pool of helper threads for the host-side packing / copy-out of the host-pointer path
+class Helpers {
+public:
+    explicit Helpers(unsigned n) : n_(n ? n : 1u) {}
+    unsigned size() const { return n_; }
+    // f(part, parts): runs on `parts` threads (the caller is one of them) and returns when all are done
+    template <class F>
+    void run(unsigned parts, F &&f) const
+    {
+        if (parts <= 1) {
+            f(0u, 1u);
+            return;
+        }
+        std::vector<std::thread> th;
+        th.reserve(parts - 1);
+        for (unsigned t = 1; t < parts; ++t) th.emplace_back([&f, t, parts] { f(t, parts); });
+        f(0u, parts);
+        for (auto &x : th) x.join();
+    }
+
+private:
+    unsigned n_;
+};
+
+constexpr int NSLOT = 3;  // ranges in flight per lane: one being packed / uploaded, one decoding, one downloading / copied out
+struct Lane {
+    hipStream_t s_k = nullptr, s_up = nullptr, s_dn = nullptr;
+    hipEvent_t ev_up[NSLOT] = {}, ev_k[NSLOT] = {}, ev_dn[NSLOT] = {};
+    Arena d_in[NSLOT], d_out[NSLOT], d_meta[NSLOT], d_gz[NSLOT];
+    Pinned h_in[NSLOT], h_out[NSLOT], h_meta[NSLOT];
+    uint32_t *d_counter = nullptr;
+    std::mutex mu;
+    bool ready = false;
+};
+
+struct Shard {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // the device-pointer path launches here (pzg_set_stream)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    uint32_t *d_counters = nullptr;  // COUNTER_SLOTS x 2 words
+    std::atomic<uint32_t> next_counter{0};
+    Arena a_adler, a_scratch, a_gz, a_order, a_dec;
+    Lane lanes[LANES_PER_SHARD];
+    std::atomic<uint32_t> next_lane{0};
+    std::mutex mu;  // device-pointer path bookkeeping (stream pointer, arenas above, timing events)
+};
 
 }  // namespace
 
 struct pzg_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    std::mutex mu;
-    Arena a_in, a_out, a_meta, a_adler, a_gz;
-    void *h_stage = nullptr;  // pinned host staging for the host-pointer path
-    size_t h_stage_cap = 0;
+    std::vector<std::unique_ptr<Shard>> shards;
+    int ring_bits = PZG_DEFAULT_RING_BITS;
+    std::mutex err_mu;
     std::string last_error;
     void *prof_buf = nullptr;  // diagnostic builds only
-    void *d_counter = nullptr; // stream-index counter of the persistent inflate waves
-    hipStream_t s_up = nullptr, s_dn = nullptr;  // host-pointer path of big batches: H2D and D2H beside the kernel stream
-    hipEvent_t ev_up[8] = {}, ev_k[8] = {}, ev_dn[8] = {};
-    int ring_bits = PZG_DEFAULT_RING_BITS;
-    int num_cus = 256;
+    std::unique_ptr<Helpers> helpers;
 };
 
 namespace {
@@ -54,13 +117,16 @@ int hip_fail(pzg_ctx *ctx, hipError_t e, const char *what)
 {
     char buf[256];
     snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-    if (ctx) ctx->last_error = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> g(ctx->err_mu);
+        ctx->last_error = buf;
+    }
     return PZG_RC_HIP_ERROR;
 }
 
-#define HIP_TRY(ctx, call)                                  \
-    do {                                                    \
-        hipError_t e_ = (call);                             \
+#define HIP_TRY(ctx, call)                                     \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
     } while (0)
 
@@ -81,29 +147,474 @@ int arena_reserve(pzg_ctx *ctx, Arena &a, size_t bytes)
     return PZG_RC_OK;
 }
 
-// the two copy streams and the per-range events of the pipelined host-pointer path, created on first use
-int ensure_pipeline(pzg_ctx *ctx)
+int pinned_reserve(pzg_ctx *ctx, Pinned &a, size_t bytes)
 {
-    if (ctx->s_up) return PZG_RC_OK;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_up, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_dn, hipStreamNonBlocking));
-    for (int c = 0; c < 8; ++c) {
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_up[c], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_k[c], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_dn[c], hipEventDisableTiming));
+    bytes = (bytes + 4095u) & ~(size_t)4095u;
+    if (a.cap >= bytes) return PZG_RC_OK;
+    if (a.p) HIP_TRY(ctx, hipHostFree(a.p));
+    a.p = nullptr;
+    a.cap = 0;
+    hipError_t e = hipHostMalloc((void **)&a.p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        hip_fail(ctx, e, "hipHostMalloc");
+        return PZG_RC_NO_MEMORY;
     }
+    a.cap = bytes;
     return PZG_RC_OK;
 }
 
-int launch_timed(pzg_ctx *ctx, const pzg::InflateArgs &args_in)
+int lane_prepare(pzg_ctx *ctx, Lane &ln)
 {
-    pzg::InflateArgs args = args_in;
-    args.counter = (uint32_t *)ctx->d_counter;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(ctx, pzg::launch_inflate(args, ctx->ring_bits, ctx->num_cus, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->timed = true;
+    if (ln.ready) return PZG_RC_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ln.s_k, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ln.s_up, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ln.s_dn, hipStreamNonBlocking));
+    for (int c = 0; c < NSLOT; ++c) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ln.ev_up[c], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ln.ev_k[c], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ln.ev_dn[c], hipEventDisableTiming));
+    }
+    if (hipMalloc((void **)&ln.d_counter, 256) != hipSuccess) return PZG_RC_NO_MEMORY;
+    ln.ready = true;
     return PZG_RC_OK;
+}
+
+void lane_destroy(Lane &ln)
+{
+    for (int c = 0; c < NSLOT; ++c) {
+        for (Arena *a : {&ln.d_in[c], &ln.d_out[c], &ln.d_meta[c], &ln.d_gz[c]})
+            if (a->p) (void)hipFree(a->p);
+        for (Pinned *p : {&ln.h_in[c], &ln.h_out[c], &ln.h_meta[c]})
+            if (p->p) (void)hipHostFree(p->p);
+        if (ln.ev_up[c]) (void)hipEventDestroy(ln.ev_up[c]);
+        if (ln.ev_k[c]) (void)hipEventDestroy(ln.ev_k[c]);
+        if (ln.ev_dn[c]) (void)hipEventDestroy(ln.ev_dn[c]);
+    }
+    if (ln.d_counter) (void)hipFree(ln.d_counter);
+    if (ln.s_k) (void)hipStreamDestroy(ln.s_k);
+    if (ln.s_up) (void)hipStreamDestroy(ln.s_up);
+    if (ln.s_dn) (void)hipStreamDestroy(ln.s_dn);
+}
+
+// every lane stream of a lane quiet again (error paths: no copy that targets caller memory may stay in flight)
+void lane_drain(Lane &ln)
+{
+    if (ln.s_up) (void)hipStreamSynchronize(ln.s_up);
+    if (ln.s_k) (void)hipStreamSynchronize(ln.s_k);
+    if (ln.s_dn) (void)hipStreamSynchronize(ln.s_dn);
+}
+
+int shard_create(pzg_ctx *ctx, int device, std::unique_ptr<Shard> &out)
+{
+    std::unique_ptr<Shard> sh(new (std::nothrow) Shard());
+    if (!sh) return PZG_RC_NO_MEMORY;
+    sh->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&sh->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&sh->ev0) != hipSuccess || hipEventCreate(&sh->ev1) != hipSuccess)
+        return PZG_RC_NO_DEVICE;
+    sh->stream = sh->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) sh->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void **)&sh->d_counters, 256 * COUNTER_SLOTS) != hipSuccess) return PZG_RC_NO_MEMORY;
+    out = std::move(sh);
+    (void)ctx;
+    return PZG_RC_OK;
+}
+
+void shard_destroy(Shard &sh)
+{
+    (void)hipSetDevice(sh.device);
+    (void)hipDeviceSynchronize();
+    for (Lane &ln : sh.lanes) lane_destroy(ln);
+    for (Arena *a : {&sh.a_adler, &sh.a_scratch, &sh.a_gz, &sh.a_order, &sh.a_dec})
+        if (a->p) (void)hipFree(a->p);
+    if (sh.d_counters) (void)hipFree(sh.d_counters);
+    if (sh.ev0) (void)hipEventDestroy(sh.ev0);
+    if (sh.ev1) (void)hipEventDestroy(sh.ev1);
+    if (sh.own_stream) (void)hipStreamDestroy(sh.own_stream);
+}
+
+int ctx_create(const std::vector<int> &devices, pzg_ctx **out)
+{
+    pzg_ctx *ctx = new (std::nothrow) pzg_ctx();
+    if (!ctx) return PZG_RC_NO_MEMORY;
+    for (int d : devices) {
+        std::unique_ptr<Shard> sh;
+        int rc = shard_create(ctx, d, sh);
+        if (rc != PZG_RC_OK) {
+            if (sh) shard_destroy(*sh);
+            for (auto &s : ctx->shards) shard_destroy(*s);
+            delete ctx;
+            return rc;
+        }
+        ctx->shards.push_back(std::move(sh));
+    }
+    if (const char *e = getenv("PZG_RING_BITS")) {  // environment override of the default size class
+        const int rb = atoi(e);
+        if (rb >= 11 && rb <= 15) ctx->ring_bits = rb;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = getenv("PZG_HOST_THREADS")) hw = (unsigned)atoi(e);
+    ctx->helpers.reset(new Helpers(hw > 24u ? 24u : hw < 1u ? 1u : hw));
+    *out = ctx;
+    return PZG_RC_OK;
+}
+
+// ---- the device-pointer path: everything already lives on shard 0's device -------------------------------------
+int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
+{
+    std::lock_guard<std::mutex> g(sh.mu);
+    HIP_TRY(ctx, hipSetDevice(sh.device));
+    const uint32_t slot = sh.next_counter.fetch_add(1u) % COUNTER_SLOTS;  // its own counter: launches on different streams may overlap
+    a.counter = sh.d_counters + 64u * slot;
+    if (flags & PZG_GZIP) {
+        int rc = arena_reserve(ctx, sh.a_gz, 8 * (size_t)a.n);
+        if (rc != PZG_RC_OK) return rc;
+        a.gzip = 1;
+        a.gz_expect = (uint32_t *)sh.a_gz.p;
+    }
+    if (flags & PZG_LPT_ORDER) {  // longest streams first: a launch permutation built on the device from out_cap[]
+        int rc = arena_reserve(ctx, sh.a_order, 4 * (size_t)a.n + 1024);
+        if (rc != PZG_RC_OK) return rc;
+        uint32_t *ord = (uint32_t *)sh.a_order.p;
+        HIP_TRY(ctx, pzg::launch_order(a.out_cap, a.n, ord + 256, ord, sh.stream));
+        a.order = ord + 256;
+    }
+#if defined(PZG_PROFILE)
+    a.prof_out = (uint64_t *)ctx->prof_buf;
+#endif
+    HIP_TRY(ctx, hipEventRecord(sh.ev0, sh.stream));
+    HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, sh.stream));
+    HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
+    sh.timed = true;
+    if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(sh.stream));
+    return PZG_RC_OK;
+}
+
+// ---- the host-pointer path on one shard, for the streams idx[0..m) of the caller's batch -----------------------
+struct HostBatch {
+    const uint8_t *in_base;
+    const uint64_t *in_off, *in_len;
+    uint8_t *out_base;
+    const uint64_t *out_off, *out_cap;
+    uint64_t *out_len;
+    int32_t *status;
+    uint32_t *detail;
+    uint64_t *in_used;
+    uint32_t *adler;
+    uint32_t flags;
+};
+
+struct Range {
+    uint32_t lo, hi;          // positions in idx[]
+    size_t in_bytes, out_bytes;  // packed sizes
+};
+
+inline size_t pad16(size_t x) { return (x + 15u) & ~(size_t)15u; }
+inline size_t pad256(size_t x) { return (x + 255u) & ~(size_t)255u; }
+
+int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, uint32_t m)
+{
+    if (m == 0) return PZG_RC_OK;
+    // the first free lane of this shard in a fixed order (a lone caller always lands on the same, warm one); if all
+    // are taken, queue on one of them
+    Lane *lane = nullptr;
+    std::unique_lock<std::mutex> lk;
+    for (int t = 0; t < LANES_PER_SHARD && !lane; ++t) {
+        std::unique_lock<std::mutex> trial(sh.lanes[t].mu, std::try_to_lock);
+        if (trial.owns_lock()) {
+            lane = &sh.lanes[t];
+            lk = std::move(trial);
+        }
+    }
+    if (!lane) {
+        lane = &sh.lanes[sh.next_lane.fetch_add(1u) % LANES_PER_SHARD];
+        lk = std::unique_lock<std::mutex>(lane->mu);
+    }
+    Lane &ln = *lane;
+    HIP_TRY(ctx, hipSetDevice(sh.device));
+    int rc = lane_prepare(ctx, ln);
+    if (rc != PZG_RC_OK) return rc;
+    const bool trace = getenv("PZG_TRACE_HOST") != nullptr;
+    const auto t_call0 = std::chrono::steady_clock::now();
+
+    // ranges of the (already ordered) stream list: a few per call, each below RANGE_MAX_OUT of packed output
+    size_t tot_in = 0, tot_out = 0;
+    for (uint32_t k = 0; k < m; ++k) {
+        tot_in += pad16(b.in_len[idx[k]]);
+        tot_out += pad16(b.out_cap[idx[k]]);
+    }
+    size_t target_out = tot_out / 6 + 1, target_in = tot_in / 6 + 1;
+    if (tot_in + tot_out < (96ull << 20) || m < 2048u) target_out = target_in = ~(size_t)0 >> 1;  // small batch: one range
+    if (target_out > RANGE_MAX_OUT) target_out = RANGE_MAX_OUT;
+    if (const char *e = getenv("PZG_HOST_RANGES")) {  // experiment knob
+        const int v = atoi(e);
+        if (v >= 1) {
+            target_out = tot_out / (size_t)v + 1;
+            target_in = tot_in / (size_t)v + 1;
+        }
+    }
+    std::vector<Range> rg;
+    {
+        Range r{0, 0, 0, 0};
+        for (uint32_t k = 0; k < m; ++k) {
+            const size_t ib = pad16(b.in_len[idx[k]]), ob = pad16(b.out_cap[idx[k]]);
+            if (r.hi > r.lo && (r.out_bytes + ob > target_out || r.in_bytes + ib > target_in)) {
+                rg.push_back(r);
+                r = Range{k, k, 0, 0};
+            }
+            r.hi = k + 1;
+            r.in_bytes += ib;
+            r.out_bytes += ob;
+        }
+        rg.push_back(r);
+    }
+    size_t max_in = 0, max_out = 0, max_n = 0;
+    for (const Range &r : rg) {
+        max_in = std::max(max_in, r.in_bytes);
+        max_out = std::max(max_out, r.out_bytes);
+        max_n = std::max(max_n, (size_t)(r.hi - r.lo));
+    }
+    // per-range meta block (u64[n] x 6 | i32 status | u32 adler | u32 detail[2n]), identical on host and device
+    const size_t meta_bytes = 64 * max_n;
+    const int nslot = (int)std::min<size_t>(rg.size(), (size_t)NSLOT);
+    for (int s = 0; s < nslot; ++s) {
+        if ((rc = arena_reserve(ctx, ln.d_in[s], max_in + 64)) != PZG_RC_OK) return rc;
+        if ((rc = arena_reserve(ctx, ln.d_out[s], max_out + 64)) != PZG_RC_OK) return rc;
+        if ((rc = arena_reserve(ctx, ln.d_meta[s], meta_bytes + 64)) != PZG_RC_OK) return rc;
+        if ((b.flags & PZG_GZIP) && (rc = arena_reserve(ctx, ln.d_gz[s], 8 * max_n + 64)) != PZG_RC_OK) return rc;
+        if ((rc = pinned_reserve(ctx, ln.h_in[s], max_in + 64)) != PZG_RC_OK) return rc;
+        if ((rc = pinned_reserve(ctx, ln.h_out[s], max_out + 64)) != PZG_RC_OK) return rc;
+        if ((rc = pinned_reserve(ctx, ln.h_meta[s], meta_bytes + 64)) != PZG_RC_OK) return rc;
+    }
+    const unsigned helpers = (tot_in + tot_out) >= (32ull << 20) ? ctx->helpers->size() : 1u;
+
+    auto meta_ptrs = [&](uint8_t *base, size_t nn, uint64_t *&ioff, uint64_t *&ilen, uint64_t *&ooff, uint64_t *&ocap, uint64_t *&olen,
+                         uint64_t *&used, int32_t *&st, uint32_t *&ad, uint32_t *&det) {
+        ioff = (uint64_t *)base;
+        ilen = ioff + nn;
+        ooff = ilen + nn;
+        ocap = ooff + nn;
+        olen = ocap + nn;
+        used = olen + nn;
+        st = (int32_t *)(used + nn);
+        ad = (uint32_t *)(st + nn);
+        det = ad + nn;
+    };
+
+    // pack the range's streams into its pinned input slot and lay out its extents
+    auto pack = [&](const Range &r, int s) {
+        const size_t nn = r.hi - r.lo;
+        uint64_t *ioff, *ilen, *ooff, *ocap, *olen, *used;
+        int32_t *st;
+        uint32_t *ad, *det;
+        meta_ptrs(ln.h_meta[s].p, nn, ioff, ilen, ooff, ocap, olen, used, st, ad, det);
+        size_t ip = 0, op = 0;
+        for (size_t q = 0; q < nn; ++q) {
+            const uint32_t i = idx[r.lo + q];
+            ioff[q] = ip;
+            ilen[q] = b.in_len[i];
+            ooff[q] = op;
+            ocap[q] = b.out_cap[i];
+            ip += pad16(b.in_len[i]);
+            op += pad16(b.out_cap[i]);
+        }
+        uint8_t *dst = ln.h_in[s].p;
+        ctx->helpers->run(helpers, [&](unsigned t, unsigned parts) {
+            const size_t q0 = nn * t / parts, q1 = nn * (t + 1) / parts;
+            for (size_t q = q0; q < q1; ++q) {
+                const uint32_t i = idx[r.lo + q];
+                if (b.in_len[i]) memcpy(dst + ioff[q], b.in_base + b.in_off[i], b.in_len[i]);
+            }
+        });
+    };
+    // hand a finished range to the caller: results, and the decoded bytes out of the pinned output slot
+    auto unpack = [&](const Range &r, int s) {
+        const size_t nn = r.hi - r.lo;
+        uint64_t *ioff, *ilen, *ooff, *ocap, *olen, *used;
+        int32_t *st;
+        uint32_t *ad, *det;
+        meta_ptrs(ln.h_meta[s].p, nn, ioff, ilen, ooff, ocap, olen, used, st, ad, det);
+        const uint8_t *src = ln.h_out[s].p;
+        ctx->helpers->run(helpers, [&](unsigned t, unsigned parts) {
+            const size_t q0 = nn * t / parts, q1 = nn * (t + 1) / parts;
+            for (size_t q = q0; q < q1; ++q) {
+                const uint32_t i = idx[r.lo + q];
+                b.out_len[i] = olen[q];
+                b.status[i] = st[q];
+                if (b.in_used) b.in_used[i] = used[q];
+                if (b.adler) b.adler[i] = ad[q];
+                if (b.detail) {
+                    b.detail[2 * (size_t)i] = det[2 * q];
+                    b.detail[2 * (size_t)i + 1] = det[2 * q + 1];
+                }
+                const uint64_t nb = olen[q] < ocap[q] ? olen[q] : ocap[q];
+                if (nb) memcpy(b.out_base + b.out_off[i], src + ooff[q], nb);
+            }
+        });
+    };
+
+    hipError_t herr = hipSuccess;
+    const char *hwhat = "";
+    double t_pack = 0, t_unpack = 0, t_wait = 0;
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+#define LANE_TRY(call)                 \
+    do {                               \
+        if (herr == hipSuccess) {      \
+            herr = (call);             \
+            if (herr != hipSuccess) hwhat = #call; \
+        }                              \
+    } while (0)
+
+    // Two host threads per call: this one packs and issues range after range; a second one waits for each range's
+    // download and copies it out to the caller.  A slot is reused once its previous occupant has been copied out.
+    const size_t R = rg.size();
+    // a one-range call keeps its three steps on ONE stream (no cross-stream events; concurrent small calls from other
+    // lanes then sit on different hardware queues and overlap); bigger ones overlap their own ranges on three streams
+    const hipStream_t s_up = R > 1 ? ln.s_up : ln.s_k, s_dn = R > 1 ? ln.s_dn : ln.s_k;
+    std::mutex pm;
+    std::condition_variable pcv;
+    size_t issued = 0, unpacked = 0;  // ranges issued / handed back so far
+    bool abort_drain = false;
+    hipError_t derr = hipSuccess;
+    auto drain = [&] {
+        (void)hipSetDevice(sh.device);
+        for (size_t c = 0; c < R; ++c) {
+            {
+                std::unique_lock<std::mutex> g(pm);
+                pcv.wait(g, [&] { return issued > c || abort_drain; });
+                if (abort_drain && issued <= c) return;
+            }
+            const int s = (int)(c % nslot);
+            auto tw = tick();
+            const hipError_t e = hipEventSynchronize(ln.ev_dn[s]);
+            t_wait += since(tw);
+            auto tu = tick();
+            if (e == hipSuccess) unpack(rg[c], s);
+            t_unpack += since(tu);
+            {
+                std::lock_guard<std::mutex> g(pm);
+                if (e != hipSuccess && derr == hipSuccess) derr = e;
+                unpacked = c + 1;
+            }
+            pcv.notify_all();
+        }
+    };
+    std::thread drainer;
+    if (R > 1) drainer = std::thread(drain);
+    bool first_kernel = true;
+    for (size_t c = 0; c < R && herr == hipSuccess; ++c) {
+        const Range &r = rg[c];
+        const int s = (int)(c % nslot);
+        const size_t nn = r.hi - r.lo;
+        if (c >= (size_t)nslot) {  // the slot's previous occupant (range c - nslot) must have left the pinned buffers
+            std::unique_lock<std::mutex> g(pm);
+            pcv.wait(g, [&] { return unpacked + nslot > c; });
+            if (derr != hipSuccess) {
+                herr = derr;
+                hwhat = "hipEventSynchronize (download)";
+                break;
+            }
+        }
+        auto tp = tick();
+        pack(r, s);
+        t_pack += since(tp);
+        uint8_t *dm = (uint8_t *)ln.d_meta[s].p;
+        LANE_TRY(hipMemcpyAsync(dm, ln.h_meta[s].p, 32 * nn, hipMemcpyHostToDevice, s_up));  // the four extent arrays
+        if (r.in_bytes) LANE_TRY(hipMemcpyAsync(ln.d_in[s].p, ln.h_in[s].p, r.in_bytes, hipMemcpyHostToDevice, s_up));
+        if (R > 1) {
+            LANE_TRY(hipEventRecord(ln.ev_up[s], s_up));
+            LANE_TRY(hipStreamWaitEvent(ln.s_k, ln.ev_up[s], 0));
+        }
+        pzg::InflateArgs a{};
+        uint64_t *ioff, *ilen, *ooff, *ocap, *olen, *used;
+        int32_t *st;
+        uint32_t *ad, *det;
+        meta_ptrs(dm, nn, ioff, ilen, ooff, ocap, olen, used, st, ad, det);
+        a.in_base = (const uint8_t *)ln.d_in[s].p;
+        a.out_base = (uint8_t *)ln.d_out[s].p;
+        a.in_off = ioff;
+        a.in_len = ilen;
+        a.out_off = ooff;
+        a.out_cap = ocap;
+        a.out_len = olen;
+        a.in_used = used;
+        a.status = st;
+        a.adler = ad;
+        a.detail = det;
+        a.n = (uint32_t)nn;
+        a.counter = ln.d_counter;
+        if (b.flags & PZG_GZIP) {
+            a.gzip = 1;
+            a.gz_expect = (uint32_t *)ln.d_gz[s].p;
+        }
+#if defined(PZG_PROFILE)
+        a.prof_out = ctx->prof_buf ? (uint64_t *)ctx->prof_buf + 16 * (size_t)r.lo : nullptr;
+#endif
+        if (first_kernel) {
+            std::lock_guard<std::mutex> g(sh.mu);
+            LANE_TRY(hipEventRecord(sh.ev0, ln.s_k));
+            first_kernel = false;
+        }
+        LANE_TRY(pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, ln.s_k));
+        if (c + 1 == R) {
+            std::lock_guard<std::mutex> g(sh.mu);
+            LANE_TRY(hipEventRecord(sh.ev1, ln.s_k));
+            sh.timed = true;
+        }
+        if (R > 1) {
+            LANE_TRY(hipEventRecord(ln.ev_k[s], ln.s_k));
+            LANE_TRY(hipStreamWaitEvent(s_dn, ln.ev_k[s], 0));
+        }
+        LANE_TRY(hipMemcpyAsync(ln.h_meta[s].p + 32 * nn, dm + 32 * nn, 32 * nn, hipMemcpyDeviceToHost, s_dn));  // results
+        if (r.out_bytes) LANE_TRY(hipMemcpyAsync(ln.h_out[s].p, ln.d_out[s].p, r.out_bytes, hipMemcpyDeviceToHost, s_dn));
+        LANE_TRY(hipEventRecord(ln.ev_dn[s], s_dn));
+        if (herr == hipSuccess) {
+            {
+                std::lock_guard<std::mutex> g(pm);
+                issued = c + 1;
+            }
+            pcv.notify_all();
+        }
+    }
+    if (R > 1) {
+        {
+            std::lock_guard<std::mutex> g(pm);
+            abort_drain = true;  // (a no-op when every range was issued: the drainer finishes them all first)
+        }
+        pcv.notify_all();
+        drainer.join();
+        if (herr == hipSuccess && derr != hipSuccess) {
+            herr = derr;
+            hwhat = "hipEventSynchronize (download)";
+        }
+    } else if (herr == hipSuccess) {
+        drain();
+        if (derr != hipSuccess) {
+            herr = derr;
+            hwhat = "hipEventSynchronize (download)";
+        }
+    }
+#undef LANE_TRY
+    if (herr != hipSuccess) {
+        lane_drain(ln);
+        return hip_fail(ctx, herr, hwhat);
+    }
+    if (trace)
+        fprintf(stderr, "[pzg] host path: %u streams, %.1f MiB in, %.1f MiB out (packed), %zu range(s), %u helper thread(s): %.1f ms "
+                "(packing %.1f on the issuing thread; on the draining thread: waiting for downloads %.1f, copy-out %.1f)\n", m, tot_in / 1048576.0,
+                tot_out / 1048576.0, R, helpers, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count(),
+                t_pack, t_wait, t_unpack);
+    return PZG_RC_OK;
+}
+
+// longest first (by capacity): the launch order inside a shard; stable, so equal streams keep the caller's order
+void lpt_order(const uint64_t *out_cap, std::vector<uint32_t> &idx)
+{
+    bool uniform = true;
+    for (size_t k = 1; k < idx.size() && uniform; ++k) uniform = out_cap[idx[k]] == out_cap[idx[0]];
+    if (!uniform) std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return out_cap[a] > out_cap[b]; });
 }
 
 }  // namespace
@@ -111,7 +622,7 @@ int launch_timed(pzg_ctx *ctx, const pzg::InflateArgs &args_in)
 extern "C" {
 
 #if defined(PZG_PROFILE)
-// diagnostic builds only: device buffer of 12 uint64 per stream the kernel fills with cycle counters
+// diagnostic builds only: device buffer of 16 uint64 per stream the kernel fills with cycle counters
 int pzg_prof_buffer(pzg_ctx *ctx, uint32_t n, uint64_t *host_out)
 {
     if (!ctx->prof_buf) { if (hipMalloc(&ctx->prof_buf, 128u * 1048576u) != hipSuccess) return -1; }
@@ -124,78 +635,72 @@ int pzg_init(int device, pzg_ctx **out)
 {
     if (!out) return PZG_RC_BAD_ARG;
     *out = nullptr;
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) return PZG_RC_NO_DEVICE;
-    if (device < 0 || device >= ndev) return PZG_RC_BAD_ARG;
-    pzg_ctx *ctx = new (std::nothrow) pzg_ctx();
-    if (!ctx) return PZG_RC_NO_MEMORY;
-    ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
-        delete ctx;
-        return PZG_RC_NO_DEVICE;
-    }
-    ctx->stream = ctx->own_stream;
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            ctx->num_cus = prop.multiProcessorCount;
-        if (const char *e = getenv("PZG_RING_BITS")) {  // environment override of the default size class
-            const int rb = atoi(e);
-            if (rb >= 11 && rb <= 15) ctx->ring_bits = rb;
-        }
-    }
-    if (hipMalloc(&ctx->d_counter, 256) != hipSuccess) {
-        delete ctx;
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) return PZG_RC_NO_DEVICE;
+        if (device < 0 || device >= ndev) return PZG_RC_BAD_ARG;
+        return ctx_create({device}, out);
+    } catch (...) {
         return PZG_RC_NO_MEMORY;
     }
-    *out = ctx;
-    return PZG_RC_OK;
 }
+
+int pzg_init_mask(uint32_t device_mask, pzg_ctx **out)
+{
+    if (!out) return PZG_RC_BAD_ARG;
+    *out = nullptr;
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) return PZG_RC_NO_DEVICE;
+        if (device_mask == 0) device_mask = ndev >= 32 ? ~0u : (1u << ndev) - 1u;  // 0 = every visible device
+        // test knob: every shard of the mask on ONE physical device (a 1-GPU box exercises the multi-shard path)
+        const char *fold = getenv("PZG_FOLD_DEVICES");
+        std::vector<int> devs;
+        for (int d = 0; d < 32; ++d)
+            if (device_mask & (1u << d)) {
+                if (!fold && d >= ndev) return PZG_RC_BAD_ARG;
+                devs.push_back(fold ? atoi(fold) : d);
+            }
+        if (devs.empty()) return PZG_RC_BAD_ARG;
+        if (fold && (atoi(fold) < 0 || atoi(fold) >= ndev)) return PZG_RC_BAD_ARG;
+        return ctx_create(devs, out);
+    } catch (...) {
+        return PZG_RC_NO_MEMORY;
+    }
+}
+
+int pzg_device_count(pzg_ctx *ctx) { return ctx ? (int)ctx->shards.size() : 0; }
 
 void pzg_shutdown(pzg_ctx *ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    for (Arena *a : {&ctx->a_in, &ctx->a_out, &ctx->a_meta, &ctx->a_adler, &ctx->a_gz})
-        if (a->p) (void)hipFree(a->p);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    if (ctx->d_counter) (void)hipFree(ctx->d_counter);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    for (int c = 0; c < 8; ++c) {
-        if (ctx->ev_up[c]) (void)hipEventDestroy(ctx->ev_up[c]);
-        if (ctx->ev_k[c]) (void)hipEventDestroy(ctx->ev_k[c]);
-        if (ctx->ev_dn[c]) (void)hipEventDestroy(ctx->ev_dn[c]);
-    }
-    if (ctx->s_up) (void)hipStreamDestroy(ctx->s_up);
-    if (ctx->s_dn) (void)hipStreamDestroy(ctx->s_dn);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    for (auto &s : ctx->shards) shard_destroy(*s);
     delete ctx;
 }
 
 int pzg_set_stream(pzg_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return PZG_RC_BAD_ARG;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->stream = (hipStream_t)hip_stream;  // NULL = the default (null) stream
+    Shard &sh = *ctx->shards[0];
+    std::lock_guard<std::mutex> g(sh.mu);
+    sh.stream = (hipStream_t)hip_stream;  // NULL = the default (null) stream
     return PZG_RC_OK;
 }
 
 int pzg_reset_stream(pzg_ctx *ctx)
 {
     if (!ctx) return PZG_RC_BAD_ARG;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->stream = ctx->own_stream;
+    Shard &sh = *ctx->shards[0];
+    std::lock_guard<std::mutex> g(sh.mu);
+    sh.stream = sh.own_stream;
     return PZG_RC_OK;
 }
 
 int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
 {
     if (!ctx) return PZG_RC_BAD_ARG;
-    std::lock_guard<std::mutex> g(ctx->mu);
     if (option == PZG_OPT_RING_BITS && value >= 11 && value <= 15) {
         ctx->ring_bits = (int)value;
         return PZG_RC_OK;
@@ -206,9 +711,11 @@ int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
 int pzg_sync(pzg_ctx *ctx)
 {
     if (!ctx) return PZG_RC_BAD_ARG;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->shards) {
+        std::lock_guard<std::mutex> g(s->mu);
+        HIP_TRY(ctx, hipSetDevice(s->device));
+        HIP_TRY(ctx, hipStreamSynchronize(s->stream));
+    }
     return PZG_RC_OK;
 }
 
@@ -221,197 +728,81 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
     if (n == 0) return PZG_RC_OK;
     if (!in_base || !in_off || !in_len || !out_off || !out_cap || !out_len || !status) return PZG_RC_BAD_ARG;
     if ((flags & PZG_ASYNC) && !(flags & PZG_DEVICE_PTRS)) return PZG_RC_BAD_ARG;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-
-    if (flags & PZG_DEVICE_PTRS) {
-        if (!out_base) return PZG_RC_BAD_ARG;
-        pzg::InflateArgs a{in_base, in_off, in_len, out_base, out_off, out_cap, out_len,
-                           status,  detail, in_used, adler,   nullptr, nullptr, nullptr, n, 0, nullptr};
-        if (flags & PZG_GZIP) {
-            int rcg = arena_reserve(ctx, ctx->a_gz, 8 * (size_t)n);
-            if (rcg != PZG_RC_OK) return rcg;
-            a.gzip = 1;
-            a.gz_expect = (uint32_t *)ctx->a_gz.p;
+    try {
+        if (flags & PZG_DEVICE_PTRS) {
+            if (!out_base || ctx->shards.size() != 1) return PZG_RC_BAD_ARG;  // device pointers belong to ONE device
+            pzg::InflateArgs a{};
+            a.in_base = in_base;
+            a.in_off = in_off;
+            a.in_len = in_len;
+            a.out_base = out_base;
+            a.out_off = out_off;
+            a.out_cap = out_cap;
+            a.out_len = out_len;
+            a.status = status;
+            a.detail = detail;
+            a.in_used = in_used;
+            a.adler = adler;
+            a.n = n;
+            return launch_device(ctx, *ctx->shards[0], a, flags);
         }
-#if defined(PZG_PROFILE)
-        a.prof_out = (uint64_t *)ctx->prof_buf;
-#endif
-        int rc = launch_timed(ctx, a);
-        if (rc != PZG_RC_OK) return rc;
-        if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        // host pointers: validate the extents (a wrapped offset + length would size an arena far too small)
+        bool any_out = false;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (in_off[i] + in_len[i] < in_off[i] || out_off[i] + out_cap[i] < out_off[i]) return PZG_RC_BAD_ARG;
+            if ((in_len[i] >> 40) || (out_cap[i] >> 40)) return PZG_RC_BAD_ARG;
+            any_out |= out_cap[i] != 0;
+        }
+        if (any_out && !out_base) return PZG_RC_BAD_ARG;
+        HostBatch b{in_base, in_off, in_len, out_base, out_off, out_cap, out_len, status, detail, in_used, adler, flags};
+        const size_t S = ctx->shards.size();
+        if (S == 1) {
+            std::vector<uint32_t> idx(n);
+            std::iota(idx.begin(), idx.end(), 0u);
+            lpt_order(out_cap, idx);
+            return host_path(ctx, *ctx->shards[0], b, idx.data(), n);
+        }
+        // several devices: longest-processing-time-first over the shards (by capacity), one host thread per shard
+        std::vector<uint32_t> all(n);
+        std::iota(all.begin(), all.end(), 0u);
+        lpt_order(out_cap, all);
+        std::vector<std::vector<uint32_t>> part(S);
+        std::vector<uint64_t> load(S, 0);
+        for (uint32_t i : all) {
+            size_t best = 0;
+            for (size_t s = 1; s < S; ++s)
+                if (load[s] < load[best]) best = s;
+            part[best].push_back(i);
+            load[best] += out_cap[i] + in_len[i] + 4096;  // (+ a per-stream constant: tiny streams are not free)
+        }
+        std::vector<int> rcs(S, PZG_RC_OK);
+        std::vector<std::thread> th;
+        for (size_t s = 1; s < S; ++s)
+            th.emplace_back([&, s] {
+                try {
+                    rcs[s] = host_path(ctx, *ctx->shards[s], b, part[s].data(), (uint32_t)part[s].size());
+                } catch (...) {
+                    rcs[s] = PZG_RC_NO_MEMORY;
+                }
+            });
+        try {
+            rcs[0] = host_path(ctx, *ctx->shards[0], b, part[0].data(), (uint32_t)part[0].size());
+        } catch (...) {
+            rcs[0] = PZG_RC_NO_MEMORY;
+        }
+        for (auto &t : th) t.join();
+        for (int rc : rcs)
+            if (rc != PZG_RC_OK) return rc;
         return PZG_RC_OK;
-    }
-
-    // host-pointer path: stage the covering byte ranges through the context's arenas.  A big batch is cut into
-    // index ranges that flow through three HIP streams -- H2D of range c+1, the kernel on range c, D2H of range
-    // c-1 into pinned staging -- while host threads copy range c-2 out to the caller's extents.
-    uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (in_off[i] < in_lo) in_lo = in_off[i];
-        if (in_off[i] + in_len[i] > in_hi) in_hi = in_off[i] + in_len[i];
-        if (out_off[i] < out_lo) out_lo = out_off[i];
-        if (out_off[i] + out_cap[i] > out_hi) out_hi = out_off[i] + out_cap[i];
-    }
-    const uint64_t in_bytes = in_hi - in_lo, out_bytes = out_hi - out_lo;
-    if (out_bytes && !out_base) return PZG_RC_BAD_ARG;
-    // keep every stream's address alignment (mod 16) on the device what it is on the host
-    const uint32_t in_skew = (uint32_t)(((uintptr_t)in_base + in_lo) & 15u);
-    const uint32_t out_skew = (uint32_t)(((uintptr_t)out_base + out_lo) & 15u);
-    int rc;
-    if ((rc = arena_reserve(ctx, ctx->a_in, in_bytes + 64)) != PZG_RC_OK) return rc;
-    if ((rc = arena_reserve(ctx, ctx->a_out, out_bytes + 64)) != PZG_RC_OK) return rc;
-    // meta layout: in_off | in_len | out_off | out_cap | out_len | in_used  (u64[n] each)
-    //              | status | adler (32-bit [n] each) | detail u32[2n]
-    const size_t N = n;
-    const size_t m_in_off = 0, m_in_len = 8 * N, m_out_off = 16 * N, m_out_cap = 24 * N, m_out_len = 32 * N,
-                 m_in_used = 40 * N, m_status = 48 * N, m_adler = 52 * N, m_detail = 56 * N, m_total = 64 * N;
-    if ((rc = arena_reserve(ctx, ctx->a_meta, m_total)) != PZG_RC_OK) return rc;
-    if ((flags & PZG_GZIP) && (rc = arena_reserve(ctx, ctx->a_gz, 8 * N)) != PZG_RC_OK) return rc;
-    if (out_bytes && ctx->h_stage_cap < out_bytes) {
-        if (ctx->h_stage) HIP_TRY(ctx, hipHostFree(ctx->h_stage));
-        ctx->h_stage = nullptr;
-        ctx->h_stage_cap = 0;
-        hipError_t e = hipHostMalloc(&ctx->h_stage, out_bytes + 64, hipHostMallocDefault);
-        if (e != hipSuccess) {
-            hip_fail(ctx, e, "hipHostMalloc");
-            return PZG_RC_NO_MEMORY;
+    } catch (const std::bad_alloc &) {
+        return PZG_RC_NO_MEMORY;
+    } catch (...) {
+        {
+            std::lock_guard<std::mutex> g(ctx->err_mu);
+            ctx->last_error = "C++ exception inside pzg_decompress_many";
         }
-        ctx->h_stage_cap = out_bytes;
+        return PZG_RC_HIP_ERROR;
     }
-    uint8_t *d_in = (uint8_t *)ctx->a_in.p + in_skew;
-    uint8_t *d_out = (uint8_t *)ctx->a_out.p + out_skew;
-    uint8_t *d_meta = (uint8_t *)ctx->a_meta.p;
-    uint8_t *stage = (uint8_t *)ctx->h_stage;
-    const bool trace = getenv("PZG_TRACE_HOST") != nullptr;
-    const auto t_call0 = std::chrono::steady_clock::now();
-
-    // index ranges: one for a small batch, four when there is enough to overlap (more only adds kernel tails:
-    // measured 91 / 83 / 79 / 77 / 78 ms for 1 / 2 / 3 / 4 / 8 ranges on the 65,536 x 32 KiB batch)
-    uint32_t nchunk = 1;
-    if (n >= 4096u && in_bytes + out_bytes >= (256ull << 20)) nchunk = 4u;
-    if (const char *e = getenv("PZG_HOST_RANGES")) {  // experiment knob
-        const int v = atoi(e);
-        if (v >= 1 && v <= 8 && (uint32_t)v <= n) nchunk = (uint32_t)v;
-    }
-    if (nchunk > 1 && ensure_pipeline(ctx) != PZG_RC_OK) nchunk = 1;
-    hipStream_t s_k = ctx->stream;                               // kernels: the context's (or the caller's) stream
-    hipStream_t s_up = nchunk > 1 ? ctx->s_up : ctx->stream;     // H2D
-    hipStream_t s_dn = nchunk > 1 ? ctx->s_dn : ctx->stream;     // D2H
-    uint32_t cthreads = 1;
-    if (out_bytes >= (64ull << 20) && n >= 64u) {
-        cthreads = std::thread::hardware_concurrency();
-        cthreads = cthreads > 8u ? 8u : cthreads < 1u ? 1u : cthreads;
-    }
-    auto copy_out = [&](uint32_t lo, uint32_t hi) {  // per-stream copies out of staging: only [out_off, out_off + min(out_len, out_cap))
-        auto part = [&](uint32_t a0, uint32_t a1) {
-            for (uint32_t i = a0; i < a1; ++i) {
-                const uint64_t nb = out_len[i] < out_cap[i] ? out_len[i] : out_cap[i];
-                if (nb) memcpy(out_base + out_off[i], stage + (out_off[i] - out_lo), nb);
-            }
-        };
-        const uint32_t m = hi - lo;
-        if (cthreads == 1 || m < 64u) {
-            part(lo, hi);
-            return;
-        }
-        std::vector<std::thread> pool;
-        for (uint32_t t = 0; t < cthreads; ++t)
-            pool.emplace_back(part, lo + (uint32_t)((uint64_t)m * t / cthreads), lo + (uint32_t)((uint64_t)m * (t + 1) / cthreads));
-        for (auto &th : pool) th.join();
-    };
-
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_off, in_off, 8 * N, hipMemcpyHostToDevice, s_up));
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_in_len, in_len, 8 * N, hipMemcpyHostToDevice, s_up));
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_off, out_off, 8 * N, hipMemcpyHostToDevice, s_up));
-    HIP_TRY(ctx, hipMemcpyAsync(d_meta + m_out_cap, out_cap, 8 * N, hipMemcpyHostToDevice, s_up));
-    struct Range {
-        uint32_t lo, hi;
-        uint64_t ilo, ihi, olo, ohi;
-    };
-    std::vector<Range> rg(nchunk);
-    for (uint32_t c = 0; c < nchunk; ++c) {
-        Range &r = rg[c];
-        r.lo = (uint32_t)((uint64_t)n * c / nchunk);
-        r.hi = (uint32_t)((uint64_t)n * (c + 1) / nchunk);
-        r.ilo = r.olo = ~0ull;
-        r.ihi = r.ohi = 0;
-        for (uint32_t i = r.lo; i < r.hi; ++i) {
-            if (in_off[i] < r.ilo) r.ilo = in_off[i];
-            if (in_off[i] + in_len[i] > r.ihi) r.ihi = in_off[i] + in_len[i];
-            if (out_off[i] < r.olo) r.olo = out_off[i];
-            if (out_off[i] + out_cap[i] > r.ohi) r.ohi = out_off[i] + out_cap[i];
-        }
-    }
-    for (uint32_t c = 0; c < nchunk; ++c) {
-        const Range &r = rg[c];
-        const size_t lo = r.lo, m = r.hi - r.lo;
-        if (r.ihi > r.ilo)
-            HIP_TRY(ctx, hipMemcpyAsync(d_in + (r.ilo - in_lo), in_base + r.ilo, r.ihi - r.ilo, hipMemcpyHostToDevice, s_up));
-        if (nchunk > 1) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_up[c], s_up));
-            HIP_TRY(ctx, hipStreamWaitEvent(s_k, ctx->ev_up[c], 0));
-        }
-        pzg::InflateArgs a{};
-        a.in_base = d_in - in_lo;  // offsets stay the caller's
-        a.out_base = d_out - out_lo;
-        a.in_off = (const uint64_t *)(d_meta + m_in_off) + lo;
-        a.in_len = (const uint64_t *)(d_meta + m_in_len) + lo;
-        a.out_off = (const uint64_t *)(d_meta + m_out_off) + lo;
-        a.out_cap = (const uint64_t *)(d_meta + m_out_cap) + lo;
-        a.out_len = (uint64_t *)(d_meta + m_out_len) + lo;
-        a.in_used = (uint64_t *)(d_meta + m_in_used) + lo;
-        a.status = (int32_t *)(d_meta + m_status) + lo;
-        a.adler = (uint32_t *)(d_meta + m_adler) + lo;
-        a.detail = (uint32_t *)(d_meta + m_detail) + 2 * lo;
-        a.order = nullptr;
-        a.prof_out = nullptr;
-#if defined(PZG_PROFILE)
-        a.prof_out = ctx->prof_buf ? (uint64_t *)ctx->prof_buf + 16 * lo : nullptr;
-#endif
-        a.n = (uint32_t)m;
-        if (flags & PZG_GZIP) {
-            a.gzip = 1;
-            a.gz_expect = (uint32_t *)ctx->a_gz.p + 2 * lo;
-        }
-        a.counter = (uint32_t *)ctx->d_counter;
-        if (c == 0) HIP_TRY(ctx, hipEventRecord(ctx->ev0, s_k));
-        HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, ctx->num_cus, s_k));
-        if (c + 1 == nchunk) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev1, s_k));
-            ctx->timed = true;
-        }
-        if (nchunk > 1) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_k[c], s_k));
-            HIP_TRY(ctx, hipStreamWaitEvent(s_dn, ctx->ev_k[c], 0));
-        }
-        HIP_TRY(ctx, hipMemcpyAsync(out_len + lo, a.out_len, 8 * m, hipMemcpyDeviceToHost, s_dn));
-        HIP_TRY(ctx, hipMemcpyAsync(status + lo, a.status, 4 * m, hipMemcpyDeviceToHost, s_dn));
-        if (in_used) HIP_TRY(ctx, hipMemcpyAsync(in_used + lo, a.in_used, 8 * m, hipMemcpyDeviceToHost, s_dn));
-        if (adler) HIP_TRY(ctx, hipMemcpyAsync(adler + lo, a.adler, 4 * m, hipMemcpyDeviceToHost, s_dn));
-        if (detail) HIP_TRY(ctx, hipMemcpyAsync(detail + 2 * lo, a.detail, 8 * m, hipMemcpyDeviceToHost, s_dn));
-        // one D2H transfer of the range's covering bytes into pinned staging
-        if (r.ohi > r.olo)
-            HIP_TRY(ctx, hipMemcpyAsync(stage + (r.olo - out_lo), d_out + (r.olo - out_lo), r.ohi - r.olo, hipMemcpyDeviceToHost, s_dn));
-        if (nchunk > 1) HIP_TRY(ctx, hipEventRecord(ctx->ev_dn[c], s_dn));
-        // while that is in flight: hand the previous range to the caller
-        if (nchunk > 1 && c >= 1) {
-            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_dn[c - 1]));
-            if (out_bytes) copy_out(rg[c - 1].lo, rg[c - 1].hi);
-        }
-    }
-    if (nchunk > 1) {
-        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_dn[nchunk - 1]));
-    } else {
-        HIP_TRY(ctx, hipStreamSynchronize(s_dn));
-    }
-    if (out_bytes) copy_out(rg[nchunk - 1].lo, rg[nchunk - 1].hi);
-    HIP_TRY(ctx, hipStreamSynchronize(s_k));
-    if (trace)
-        fprintf(stderr, "[pzg] host path: %u streams, %.1f MiB in, %.1f MiB out, %u range(s), %u copy thread(s): %.1f ms\n", n,
-                in_bytes / 1048576.0, out_bytes / 1048576.0, nchunk, cthreads,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count());
-    return PZG_RC_OK;
 }
 
 int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap,
@@ -419,52 +810,77 @@ int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len, uint8_t *ou
 {
     if (!out_len || !status) return PZG_RC_BAD_ARG;
     static const uint8_t dummy_in = 0;
-    static uint8_t dummy_out = 0;
     const uint64_t zero = 0;
-    return pzg_decompress_many(ctx, in ? in : &dummy_in, &zero, &in_len, out ? out : &dummy_out, &zero, &out_cap,
-                               out_len, status, detail, in_used, nullptr, 1, 0);
+    if (!out) out_cap = 0;  // count only: nothing is stored
+    if (!in) in_len = 0;
+    return pzg_decompress_many(ctx, in ? in : &dummy_in, &zero, &in_len, out, &zero, &out_cap, out_len, status, detail, in_used,
+                               nullptr, 1, 0);
 }
 
 int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *out, uint32_t flags)
 {
     if (!ctx || !out || (!buf && len)) return PZG_RC_BAD_ARG;
     if ((flags & PZG_ASYNC) && !(flags & PZG_DEVICE_PTRS)) return PZG_RC_BAD_ARG;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc;
-    if ((rc = arena_reserve(ctx, ctx->a_adler, 12 * (size_t)(ADLER_MAX_WAVES + 4) + 16)) != PZG_RC_OK) return rc;
-    uint32_t *partials = (uint32_t *)ctx->a_adler.p;
-    uint32_t *d_res = partials + 3 * (size_t)(ADLER_MAX_WAVES + 4);
-    hipStream_t s = ctx->stream;
-    if (flags & PZG_DEVICE_PTRS) {
-        HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
-        HIP_TRY(ctx, pzg::launch_adler32(buf, len, init, partials, ADLER_MAX_WAVES, out, s));
-        HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
-        ctx->timed = true;
-        if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(s));
+    try {
+        Shard &sh = *ctx->shards[0];
+        std::lock_guard<std::mutex> g(sh.mu);
+        HIP_TRY(ctx, hipSetDevice(sh.device));
+        int rc;
+        if ((rc = arena_reserve(ctx, sh.a_adler, 12 * (size_t)(ADLER_MAX_WAVES + 4) + 16)) != PZG_RC_OK) return rc;
+        uint32_t *partials = (uint32_t *)sh.a_adler.p;
+        uint32_t *d_res = partials + 3 * (size_t)(ADLER_MAX_WAVES + 4);
+        hipStream_t s = sh.stream;
+        if (flags & PZG_DEVICE_PTRS) {
+            HIP_TRY(ctx, hipEventRecord(sh.ev0, s));
+            HIP_TRY(ctx, pzg::launch_adler32(buf, len, init, partials, ADLER_MAX_WAVES, out, s));
+            HIP_TRY(ctx, hipEventRecord(sh.ev1, s));
+            sh.timed = true;
+            if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(s));
+            return PZG_RC_OK;
+        }
+        const uint32_t skew = (uint32_t)((uintptr_t)buf & 15u);
+        if ((rc = arena_reserve(ctx, sh.a_scratch, len + 64)) != PZG_RC_OK) return rc;
+        uint8_t *d_buf = (uint8_t *)sh.a_scratch.p + skew;
+        if (len) HIP_TRY(ctx, hipMemcpyAsync(d_buf, buf, len, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipEventRecord(sh.ev0, s));
+        HIP_TRY(ctx, pzg::launch_adler32(d_buf, len, init, partials, ADLER_MAX_WAVES, d_res, s));
+        HIP_TRY(ctx, hipEventRecord(sh.ev1, s));
+        sh.timed = true;
+        HIP_TRY(ctx, hipMemcpyAsync(out, d_res, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
         return PZG_RC_OK;
+    } catch (...) {
+        return PZG_RC_NO_MEMORY;
     }
-    const uint32_t skew = (uint32_t)((uintptr_t)buf & 15u);
-    if ((rc = arena_reserve(ctx, ctx->a_in, len + 64)) != PZG_RC_OK) return rc;
-    uint8_t *d_buf = (uint8_t *)ctx->a_in.p + skew;
-    if (len) HIP_TRY(ctx, hipMemcpyAsync(d_buf, buf, len, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, s));
-    HIP_TRY(ctx, pzg::launch_adler32(d_buf, len, init, partials, ADLER_MAX_WAVES, d_res, s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, s));
-    ctx->timed = true;
-    HIP_TRY(ctx, hipMemcpyAsync(out, d_res, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+}
+
+int pzg_adler32_many(pzg_ctx *ctx, const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t *out, uint32_t n,
+                     uint32_t flags)
+{
+    if (!ctx || !base || !off || !len || !out) return PZG_RC_BAD_ARG;
+    if (!(flags & PZG_DEVICE_PTRS) || ctx->shards.size() != 1) return PZG_RC_BAD_ARG;  // device-resident batches only
+    if (n == 0) return PZG_RC_OK;
+    Shard &sh = *ctx->shards[0];
+    std::lock_guard<std::mutex> g(sh.mu);
+    HIP_TRY(ctx, hipSetDevice(sh.device));
+    HIP_TRY(ctx, hipEventRecord(sh.ev0, sh.stream));
+    HIP_TRY(ctx, pzg::launch_adler32_many(base, off, len, out, n, sh.num_cus, sh.stream));
+    HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
+    sh.timed = true;
+    if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(sh.stream));
     return PZG_RC_OK;
 }
 
 double pzg_last_kernel_ms(pzg_ctx *ctx)
 {
     if (!ctx) return -1.0;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    if (!ctx->timed) return -1.0;
-    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    Shard &sh = *ctx->shards[0];
+    std::lock_guard<std::mutex> g(sh.mu);
+    if (!sh.timed) return -1.0;
+    if (hipSetDevice(sh.device) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(sh.ev1) != hipSuccess) return -1.0;
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, sh.ev0, sh.ev1) != hipSuccess) return -1.0;
     return (double)ms;
 }
 
@@ -480,7 +896,14 @@ const char *pzg_strerror(int rc)
     }
 }
 
-const char *pzg_last_error(pzg_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char *pzg_last_error(pzg_ctx *ctx)
+{
+    if (!ctx) return "";
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    copy = ctx->last_error;
+    return copy.c_str();
+}
 
 uint32_t pzg_version(void) { return (PZG_VERSION_MAJOR << 16) | PZG_VERSION_MINOR; }
 

@@ -416,4 +416,118 @@ hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint3
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adler-32 of MANY buffers (the batched form of BASELINE config 2: 262,144 x 64 KiB): one wave per buffer, the same
+// 16-byte vectors, lane sums and block fold as adler32_partial_kernel; a persistent grid strides over the buffers.
+__global__ __launch_bounds__(256) void adler32_many_kernel(const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t *out,
+                                                          uint32_t n)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t i = wave; i < n; i += nwaves) {
+        const uint8_t *buf = base + off[i];
+        const uint64_t blen = len[i];
+        const uint32_t head_pad = (uint32_t)((uintptr_t)buf & 15u);
+        const u32x4 *vbase = (const u32x4 *)(buf - head_pad);
+        const uint64_t padded = head_pad + blen;
+        const uint64_t nvec = blen ? (padded + 15u) >> 4 : 0u;
+        uint32_t tail_valid = (uint32_t)(padded & 15u);
+        if (tail_valid == 0) tail_valid = 16;
+        uint32_t SA = 0, SB = 0;
+        for (uint64_t v0 = 0; v0 < nvec; v0 += AD_BLOCK_VECS) {
+            const uint32_t nv = (uint32_t)((nvec - v0) < AD_BLOCK_VECS ? (nvec - v0) : AD_BLOCK_VECS);
+            uint32_t a_l = 0, w_l = 0, u_l = 0;
+            const bool edge = v0 == 0 || v0 + nv == nvec;
+            if (!edge) {
+                const u32x4 *p = vbase + v0 + lane;
+                for (uint32_t it = 0; it < AD_BLOCK_VECS / 64u; it += AD_UNROLL) {
+                    u32x4 v[AD_UNROLL];
+#pragma unroll
+                    for (uint32_t q = 0; q < AD_UNROLL; ++q) v[q] = __builtin_nontemporal_load(p + (size_t)(it + q) * 64u);
+#pragma unroll
+                    for (uint32_t q = 0; q < AD_UNROLL; ++q) adler_acc(v[q], it + q, a_l, w_l, u_l);
+                }
+            } else {
+                for (uint32_t it = 0; it * 64u < nv; ++it) {
+                    const uint32_t j = it * 64u + lane;
+                    if (j < nv) {
+                        u32x4 v = __builtin_nontemporal_load(vbase + v0 + j);
+                        const uint64_t gv = v0 + j;
+                        const uint32_t lo = gv == 0 ? head_pad : 0u, hi = gv == nvec - 1 ? tail_valid : 16u;
+                        if (lo != 0u || hi != 16u) v = mask_vec(v, lo, hi);
+                        adler_acc(v, it, a_l, w_l, u_l);
+                    }
+                }
+            }
+            const uint32_t nb = nv * 16u;
+            int64_t bl = ((int64_t)nb - 16 * (int64_t)lane - 16) * (int64_t)a_l + (int64_t)w_l - 1024 * (int64_t)u_l;
+            const uint32_t blk_b = wave_sum((uint32_t)((uint64_t)bl % ADLER_MOD));
+            const uint32_t blk_a = wave_sum(a_l) % ADLER_MOD;
+            SB = (uint32_t)(((uint64_t)SB + (uint64_t)(nb % ADLER_MOD) * SA + blk_b) % ADLER_MOD);
+            SA = (SA + blk_a) % ADLER_MOD;
+        }
+        if (lane == 0) {
+            const uint32_t tail_pad = 16u - tail_valid;  // zero bytes behind the buffer: every weight is that much too large
+            SB = (uint32_t)(((uint64_t)SB + (uint64_t)ADLER_MOD * 16u - (uint64_t)tail_pad * SA) % ADLER_MOD);
+            const uint32_t A = (1u + SA) % ADLER_MOD;                                   // Adler32.hs:22-27 from the initial (1, 0)
+            const uint32_t B = (uint32_t)(((blen % ADLER_MOD) + SB) % ADLER_MOD);
+            out[i] = blen ? (B << 16) | A : 1u;
+        }
+    }
+}
+
+hipError_t launch_adler32_many(const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t *out, uint32_t n, int num_cus,
+                               hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    uint32_t wgs = (uint32_t)num_cus * 8u;  // 32 waves per CU
+    if (wgs > (n + 3u) / 4u) wgs = (n + 3u) / 4u;
+    hipLaunchKernelGGL(adler32_many_kernel, dim3(wgs), dim3(256), 0, stream, base, off, len, out, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch order for the persistent stream-waves: longest streams first (by capacity), so the tail of a mixed batch is
+// filled by short streams instead of waiting for one long one.  A counting sort over the 64 power-of-two size
+// classes, descending; inside a class the order is whatever the atomics give (the sizes are within 2x).
+__global__ __launch_bounds__(256) void order_hist_kernel(const uint64_t *out_cap, uint32_t n, uint32_t *hist)
+{
+    __shared__ uint32_t h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t c = out_cap[i];
+        atomicAdd(&h[c ? (uint32_t)__builtin_clzll(c) : 63u], 1u);  // class 0 = the largest
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(64) void order_scan_kernel(uint32_t *hist)  // hist[0..64) -> cursors in hist[64..128)
+{
+    uint32_t v = hist[threadIdx.x], incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64);
+        if ((int)threadIdx.x >= o) incl += y;
+    }
+    hist[64 + threadIdx.x] = incl - v;
+}
+__global__ __launch_bounds__(256) void order_scatter_kernel(const uint64_t *out_cap, uint32_t n, uint32_t *hist, uint32_t *order)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t c = out_cap[i];
+        order[atomicAdd(&hist[64u + (c ? (uint32_t)__builtin_clzll(c) : 63u)], 1u)] = i;
+    }
+}
+
+hipError_t launch_order(const uint64_t *out_cap, uint32_t n, uint32_t *order, uint32_t *scratch, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(scratch, 0, 128 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t wgs = n < 256u * 1024u ? (n + 255u) / 256u : 1024u;
+    hipLaunchKernelGGL(order_hist_kernel, dim3(wgs), dim3(256), 0, stream, out_cap, n, scratch);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, stream, scratch);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(wgs), dim3(256), 0, stream, out_cap, n, scratch, order);
+    return hipGetLastError();
+}
+
 }  // namespace pzg

@@ -31,4 +31,11 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
 hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *partials, uint32_t max_waves,
                           uint32_t *out, hipStream_t stream);
 
+// Adler-32 of n buffers base + off[i] .. + len[i] (device memory), one wave per buffer
+hipError_t launch_adler32_many(const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t *out, uint32_t n, int num_cus,
+                               hipStream_t stream);
+
+// order[0..n): stream indices, longest (by out_cap) first; scratch: 128 uint32 of device memory
+hipError_t launch_order(const uint64_t *out_cap, uint32_t n, uint32_t *order, uint32_t *scratch, hipStream_t stream);
+
 }  // namespace pzg

@@ -195,7 +195,7 @@ inline std::vector<Either> decompressMany(const std::vector<LazyByteString> &inp
     std::vector<uint64_t> caps(n);
     for (size_t i = 0; i < n; ++i) {
         flat[i] = toStrict(inputs[i]);
-        caps[i] = size_hint ? (*size_hint)[i] : (flat[i].size() * 4 > 65536 ? flat[i].size() * 4 : 65536);
+        caps[i] = size_hint ? (*size_hint)[i] : (flat[i].size() * 4 > 256 ? flat[i].size() * 4 : 256);  // a modest first guess: too-small streams are relaunched with their exact size
     }
     std::vector<size_t> todo(n);
     for (size_t i = 0; i < n; ++i) todo[i] = i;

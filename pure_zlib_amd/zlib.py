@@ -137,13 +137,22 @@ def error_from_status(stream: bytes, status: int, detail) -> DecompressionError:
 class Context:
     """One pzg_ctx (HIP device + stream + staging arenas)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, device_mask: Optional[int] = None):
+        """device: one HIP device.  device_mask: several devices of one node (bit d = device d, 0 = all visible):
+        decompress_many then shards a host batch over them inside the library (pzg_init_mask)."""
         L = _ffi.lib()
         h = C.c_void_p()
-        _ffi.check(L.pzg_init(device, C.byref(h)))
+        if device_mask is None:
+            _ffi.check(L.pzg_init(device, C.byref(h)))
+        else:
+            _ffi.check(L.pzg_init_mask(device_mask, C.byref(h)))
         self._h = h
         self._L = L
         self.device = device
+
+    @property
+    def device_count(self) -> int:
+        return int(self._L.pzg_device_count(self._h))
 
     def close(self):
         if self._h:
@@ -203,8 +212,8 @@ class Context:
     # -- device-pointer call (the timed path; pointers are raw integers) ----------------------------
     def decompress_many_device(self, in_base: int, in_off: int, in_len: int, out_base: int, out_off: int,
                                out_cap: int, out_len: int, status: int, detail: int, in_used: int, adler: int,
-                               n: int, sync: bool = True, gzip: bool = False):
-        flags = _ffi.DEVICE_PTRS | (0 if sync else _ffi.ASYNC) | (_ffi.GZIP if gzip else 0)
+                               n: int, sync: bool = True, gzip: bool = False, lpt: bool = False):
+        flags = _ffi.DEVICE_PTRS | (0 if sync else _ffi.ASYNC) | (_ffi.GZIP if gzip else 0) | (_ffi.LPT_ORDER if lpt else 0)
         rc = self._L.pzg_decompress_many(self._h, in_base, in_off, in_len, out_base, out_off, out_cap, out_len,
                                          status, detail or None, in_used or None, adler or None, n, flags)
         _ffi.check(rc, self._h)
@@ -215,6 +224,11 @@ class Context:
         ptr = arr.ctypes.data if arr.size else None
         _ffi.check(self._L.pzg_adler32(self._h, ptr, arr.size, init, C.byref(out), 0), self._h)
         return out.value
+
+    def adler32_many_device(self, base: int, off: int, length: int, out_ptr: int, n: int, sync: bool = True):
+        """Adler-32 of n device buffers (one wave each): BASELINE config 2 in its batched form."""
+        flags = _ffi.DEVICE_PTRS | (0 if sync else _ffi.ASYNC)
+        _ffi.check(self._L.pzg_adler32_many(self._h, base, off, length, out_ptr, n, flags), self._h)
 
     def adler32_device(self, ptr: int, nbytes: int, out_ptr: int, init: int = 1, sync: bool = True):
         flags = _ffi.DEVICE_PTRS | (0 if sync else _ffi.ASYNC)
@@ -259,7 +273,9 @@ def decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = 
     flat = [b"".join(c) for c in chunked]
     n = len(flat)
     results: List[Optional[Either]] = [None] * n
-    caps = [int(size_hint[i]) if size_hint is not None else max(1 << 16, 4 * len(flat[i])) for i in range(n)]
+    # without a hint: a modest first guess (the batch is packed, so small guesses cost little); PZG_E_OUT_TOO_SMALL
+    # streams come back with their exact size and are relaunched once
+    caps = [int(size_hint[i]) if size_hint is not None else max(256, 4 * len(flat[i])) for i in range(n)]
     todo = list(range(n))
     for _attempt in range(2):
         if not todo:

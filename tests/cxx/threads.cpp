@@ -1,6 +1,7 @@
 // threads.cpp -- several host threads share one pzg_ctx (the library locks it internally: SURVEY.md 8b "Threading") and
 // decode the reference fixtures concurrently; every result must be right.  Usage: threads <name.z> <name.gold> ...
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,8 +35,8 @@ int main(int argc, char **argv)
         golds.push_back(slurp(argv[i + 1]));
     }
     std::atomic<int> bad{0}, done{0};
-    auto worker = [&](int t) {
-        for (int rep = 0; rep < 20; ++rep) {
+    auto worker = [&](int t, int reps) {
+        for (int rep = 0; rep < reps; ++rep) {
             const size_t k = (size_t)(t * 7 + rep) % zs.size();
             std::vector<uint8_t> out(golds[k].size() + 64);
             uint64_t out_len = 0, in_used = 0;
@@ -47,10 +48,21 @@ int main(int argc, char **argv)
             ++done;
         }
     };
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    for (int t = 0; t < 3; ++t) worker(t, 3);  // warm every pipeline of the context (streams, arenas, staging)
+    done = 0;
+    // the same 160 calls from one thread, then from eight
+    const auto t0 = now();
+    for (int t = 0; t < 8; ++t) worker(t, 20);
+    const double serial = std::chrono::duration<double>(now() - t0).count();
+    done = 0;
+    const auto t1 = now();
     std::vector<std::thread> pool;
-    for (int t = 0; t < 8; ++t) pool.emplace_back(worker, t);
+    for (int t = 0; t < 8; ++t) pool.emplace_back(worker, t, 20);
     for (auto &th : pool) th.join();
+    const double threaded = std::chrono::duration<double>(now() - t1).count();
     pzg_shutdown(ctx);
     printf("threads: %d calls from 8 threads, %d bad\n", done.load(), bad.load());
+    printf("one thread %.1f ms, eight threads %.1f ms, speed-up over one thread: %.2fx\n", serial * 1e3, threaded * 1e3, serial / threaded);
     return bad ? 1 : 0;
 }

@@ -67,7 +67,7 @@ class DeviceBatch:
         if len(widths) == 1:  # equal sizes: compare on the device
             width = widths.pop()
             stride = (width + 255) // 256 * 256
-            pool_t = t.from_numpy(np.frombuffer(b"".join(self.texts), dtype=np.uint8).reshape(len(self.texts), width)).to(self.dev)
+            pool_t = t.from_numpy(np.frombuffer(b"".join(self.texts), dtype=np.uint8).reshape(len(self.texts), width).copy()).to(self.dev)
             got = self.d_out.view(self.n, stride)
             idx = t.from_numpy(self.pick).to(self.dev)
             for lo in range(0, self.n, 8192):

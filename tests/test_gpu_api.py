@@ -1,0 +1,147 @@
+"""GPU tests of the C ABI beyond the single decode call: in-library multi-device sharding, the
+device-side launch order, the batched Adler-32 (BASELINE config 2's second form), argument validation, and
+several host threads on one context."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+from conftest import REF_CASES, ROOT
+from test_gpu_parity import run_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_batch(n):
+    datas = [corpus.zipf_text(200 + (k * 7919) % 60000, k) if k % 3 else corpus.mixed_data((k * 131) % 9000, k) for k in range(n)]
+    return [zlib.compress(d, 1 + k % 9) for k, d in enumerate(datas)], datas
+
+
+def test_decompress_many_sharded_over_a_device_mask(gpu_ctx, oracle, monkeypatch):
+    """pzg_init_mask: ONE pzg_decompress_many call partitions the streams over the mask's devices (here four shards
+    folded onto device 0 by the test knob, so the multi-shard path -- one host thread, stream set and arenas per shard,
+    results written straight into the caller's slots -- runs on a 1-GPU box).  Byte-identical to the single-device
+    result and to the oracle."""
+    import pure_zlib_amd as P
+    monkeypatch.setenv("PZG_FOLD_DEVICES", "0")
+    group = P.Context(device_mask=0b1111)
+    try:
+        assert group.device_count == 4 and gpu_ctx.device_count == 1
+        streams, datas = _mixed_batch(3000)
+        streams += [streams[5][:-7], b"\x78\x9d\x01", streams[9][:40] + b"\xff" * 9 + streams[9][49:]]  # and a few bad ones
+        datas += [b"", b"", b""]
+        caps = [len(d) + 16 for d in datas]
+        one, outs1, _, _ = run_batch(gpu_ctx, streams, caps)
+        many, outsN, _, _ = run_batch(group, streams, caps)
+        for a, b in zip(one, many):
+            assert np.array_equal(a, b)
+        assert outs1 == outsN
+        for k in range(0, len(streams), 37):
+            r, o = oracle.decompress(streams[k], caps[k])
+            assert int(many[1][k]) == r.status
+            if r.status == 0:
+                assert outsN[k] == o and int(many[4][k]) == r.adler
+        # the mirror API on the group context
+        rs = P.decompress_many(streams[:200], ctx=group)
+        assert rs == [P.Right(d) for d in datas[:200]]
+        # device pointers belong to one device: refused on a multi-device context
+        from pure_zlib_amd._ffi import PzgError
+        with pytest.raises(PzgError):
+            group.decompress_many_device(1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1)
+    finally:
+        group.close()
+
+
+def test_device_side_launch_order(gpu_ctx):
+    """PZG_LPT_ORDER: the longest-first launch permutation built on the device changes nothing but the order."""
+    from devbatch import DeviceBatch
+    texts = [corpus.zipf_text(1024 * (1 + (s * 2654435761 >> 7) % 64), s) for s in range(256)]
+    zs = [zlib.compress(t, 6) for t in texts]
+    pick = np.random.default_rng(11).integers(0, len(zs), size=20000)
+    b = DeviceBatch(texts, zs, pick)
+    res = b.run(gpu_ctx, 11)
+    b.check_all(*res)
+    import torch
+    b.d_out.fill_(0xCD)
+    b.d_status.fill_(-1)
+    torch.cuda.synchronize()
+    gpu_ctx.decompress_many_device(b.d_in.data_ptr(), b.d_in_off.data_ptr(), b.d_in_len.data_ptr(), b.d_out.data_ptr(),
+                                   b.d_out_off.data_ptr(), b.d_out_cap.data_ptr(), b.d_out_len.data_ptr(), b.d_status.data_ptr(),
+                                   b.d_detail.data_ptr(), b.d_in_used.data_ptr(), b.d_adler.data_ptr(), b.n, sync=True, lpt=True)
+    b.check_all(b.d_status.cpu().numpy(), b.d_out_len.cpu().numpy(), b.d_in_used.cpu().numpy(), b.d_adler.cpu().numpy().view(np.uint32))
+
+
+def test_adler32_many_batched(gpu_ctx):
+    """BASELINE config 2, batched form: one wave per buffer; every length class, every 16-byte alignment."""
+    import torch
+    rng = np.random.default_rng(2)
+    lens = [0, 1, 15, 16, 17, 255, 4096, 65535, 65536, 65537, 100001, 1 << 20] * 20 + [65536] * 2048
+    off, pos = [], 0
+    for k, n in enumerate(lens):
+        pos += k % 16 if k < 400 else 0  # unaligned starts
+        off.append(pos)
+        pos += n
+    buf = rng.integers(0, 256, size=pos + 64, dtype=np.uint8)
+    dev = torch.device("cuda", 0)
+    d_buf = torch.from_numpy(buf).to(dev)
+    d_off = torch.tensor(off, dtype=torch.int64, device=dev)
+    d_len = torch.tensor(lens, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(len(lens), dtype=torch.int32, device=dev)
+    gpu_ctx.adler32_many_device(d_buf.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), d_out.data_ptr(), len(lens))
+    got = d_out.cpu().numpy().view(np.uint32)
+    for k, n in enumerate(lens):
+        assert int(got[k]) == zlib.adler32(buf[off[k]:off[k] + n].tobytes()), (k, n)
+
+
+def test_argument_validation(gpu_ctx):
+    """Wrapped extents and NULL outputs are refused or handled, never followed."""
+    L = gpu_ctx._L
+    z = zlib.compress(b"hello world" * 100)
+    zb = np.frombuffer(z, dtype=np.uint8)
+    out = np.zeros(4096, dtype=np.uint8)
+    u64 = lambda *v: np.array(v, dtype=np.uint64)  # noqa: E731
+    olen, st = u64(0), np.array([0], dtype=np.int32)
+
+    def call(in_off, in_len, out_off, out_cap, outp=out):
+        return L.pzg_decompress_many(gpu_ctx.handle, zb.ctypes.data, in_off.ctypes.data, in_len.ctypes.data,
+                                     outp.ctypes.data if outp is not None else None, out_off.ctypes.data, out_cap.ctypes.data,
+                                     olen.ctypes.data, st.ctypes.data, None, None, None, 1, 0)
+    assert call(u64(0), u64(len(z)), u64(0), u64(4096)) == 0 and st[0] == 0 and olen[0] == 1100
+    assert call(u64(2**64 - 8), u64(64), u64(0), u64(4096)) == -1          # in_off + in_len wraps
+    assert call(u64(0), u64(len(z)), u64(2**64 - 16), u64(4096)) == -1      # out_off + out_cap wraps
+    assert call(u64(0), u64(len(z)), u64(0), u64(4096), None) == -1         # capacity but no output pointer
+    # the single-stream form with no output buffer: counts, stores nothing
+    ol, s2, used = C.c_uint64(0), C.c_int32(-1), C.c_uint64(0)
+    rc = L.pzg_decompress(gpu_ctx.handle, zb.ctypes.data, len(z), None, 12345, C.byref(ol), C.byref(s2), None, C.byref(used))
+    assert rc == 0 and s2.value == 14 and ol.value == 1100
+
+
+def test_many_tiny_streams_through_the_mirror_without_size_hints(gpu_ctx):
+    """200,000 tiny streams and no size hints: the first-pass capacities stay small (the batch is packed, not the
+    covering range of 64 KiB slots), streams that need more are relaunched with their exact size."""
+    import pure_zlib_amd as P
+    datas = [str(k).encode() * (1 + k % 9) for k in range(200000)]
+    datas[777] = corpus.zipf_text(300000, 1)  # one that outgrows any first guess
+    zs = [zlib.compress(d, 6) for d in datas]
+    rs = P.decompress_many(zs, ctx=gpu_ctx)
+    assert all(r == P.Right(d) for r, d in zip(rs, datas))
+
+
+def test_cxx_threads_overlap_on_one_context():
+    """SURVEY 8b "Threading": eight host threads on ONE context -- every result right, and the calls overlap (each takes
+    its own pipeline of the context) instead of queueing behind one lock."""
+    exe = os.path.join(ROOT, "tests", "cxx", "threads")
+    src = os.path.join(ROOT, "tests", "cxx", "threads.cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", src, "-o", exe, "-L" + os.path.join(ROOT, "pure_zlib_amd"),
+                           "-lpzg", "-Wl,-rpath," + os.path.join(ROOT, "pure_zlib_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    args = []
+    for n in REF_CASES:
+        args += [os.path.join(ROOT, "tests", "golden", "ref", n + ".z"), os.path.join(ROOT, "tests", "golden", "ref", n + ".gold")]
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "160 calls from 8 threads, 0 bad" in out.stdout, out.stdout + out.stderr
+    speedup = float(out.stdout.split("speed-up over one thread:")[1].split("x")[0])
+    assert speedup > 1.15, out.stdout

@@ -370,16 +370,3 @@ def test_large_stream_and_many_tiny_streams(ctx):
     tiny_z = [zlib.compress(d, 1 + k % 9) for k, d in enumerate(tiny_d)]
     (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, tiny_z, [len(d) for d in tiny_d])
     assert (status == 0).all() and all(o == d for o, d in zip(outs, tiny_d))
-
-
-def test_cxx_threads_share_one_context():
-    """SURVEY 8b "Threading": eight host threads call pzg_decompress on ONE context concurrently (tests/cxx/threads.cpp)."""
-    exe = os.path.join(ROOT, "tests", "cxx", "threads")
-    src = os.path.join(ROOT, "tests", "cxx", "threads.cpp")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", src, "-o", exe, "-L" + os.path.join(ROOT, "pure_zlib_amd"),
-                           "-lpzg", "-Wl,-rpath," + os.path.join(ROOT, "pure_zlib_amd"), "-Wl,-rpath,/opt/rocm/lib"])
-    args = []
-    for n in REF_CASES:
-        args += [os.path.join(ROOT, "tests", "golden", "ref", n + ".z"), os.path.join(ROOT, "tests", "golden", "ref", n + ".gold")]
-    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "160 calls from 8 threads, 0 bad" in out.stdout, out.stdout + out.stderr
