@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define PZG_VERSION_MAJOR 0
-#define PZG_VERSION_MINOR 1
+#define PZG_VERSION_MINOR 2
 
 /* ---- call-level return codes (the int every function returns) ---------------- */
 #define PZG_RC_OK            0
@@ -67,6 +67,13 @@ extern "C" {
 #define PZG_E_GZIP_HEADER        18  /* "Header error: gzip: ..."; d0 = 1 bad magic, 2 method != 8, 3 reserved flag bits, 4 header CRC16 */
 #define PZG_E_GZIP_ISIZE         19  /* "Checksum error: gzip: length mismatch: <d0> != <d1>" (ISIZE vs bytes produced mod 2^32);
                                       * a CRC-32 mismatch is PZG_E_CHECKSUM.  Not checked for PZG_E_OUT_TOO_SMALL streams. */
+
+/* pzg_decompress_many_dict only (extension): */
+#define PZG_E_DICT               20  /* "Header error: preset dictionary mismatch: <hex d0> != <hex d1>": the stream's DICTID (d0) is
+                                      * not the Adler-32 of the dictionary supplied for it (d1) */
+/* pzg_decoder_feed only: a decoder that is not finished */
+#define PZG_DEC_NEED_INPUT      101  /* NeedMore (Monad.hs:164): every complete element of the input has been decoded */
+#define PZG_DEC_OUT_FULL        102  /* this call's output room is used up: call again with the rest of the input */
 
 /* tree ids in detail[2*i] of PZG_E_HUFF_BUILD */
 #define PZG_TREE_CODELEN 0
@@ -138,6 +145,50 @@ int pzg_decompress_many(pzg_ctx *ctx,
                         uint64_t *out_len, int32_t *status, uint32_t *detail,
                         uint64_t *in_used, uint32_t *adler,
                         uint32_t n, uint32_t flags);
+
+/*
+ * EXTENSION -- preset dictionaries (RFC 1950 FDICT).  The reference skips DICTID and decodes with an empty history
+ * (Zlib.hs:68, a FIXME there); pzg_decompress_many does exactly that.  This entry point is the same call plus one
+ * dictionary extent per stream (dict_len[i] = 0: none): a stream whose header has FDICT set and that has a
+ * dictionary checks DICTID against the dictionary's Adler-32 (PZG_E_DICT) and decodes with the dictionary as the
+ * history in front of its output; every other stream behaves as in pzg_decompress_many.  dict_* may be NULL.
+ */
+int pzg_decompress_many_dict(pzg_ctx *ctx,
+                             const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len,
+                             const uint8_t *dict_base, const uint64_t *dict_off, const uint64_t *dict_len,
+                             uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap,
+                             uint64_t *out_len, int32_t *status, uint32_t *detail,
+                             uint64_t *in_used, uint32_t *adler,
+                             uint32_t n, uint32_t flags);
+
+/*
+ * decompressIncremental / ZlibDecoder (Zlib.hs:3-8, Monad.hs:163-197; driver Deflate.hs:30-48), batched: a pzg_decoder
+ * is n suspended zlib decoders living on the device (a one-device context).  pzg_decoder_feed continues the decoders
+ * idx[0..m) (idx = NULL: all n, m ignored) -- one launch, one wavefront per decoder -- as far as their input and
+ * output room go.  For decoder k = idx[j]:
+ *   in_base + in_off[j] .. + in_len[j]   the bytes the last call did not consume (from its in_used on) followed by
+ *                                        the new input; final_in[j] != 0 (array may be NULL): no more input will follow
+ *   out_base + out_off[j] .. + out_cap[j]  room for the bytes this call delivers (out_cap >= 4096); out_len[j] of them
+ *   state[j]     PZG_DEC_NEED_INPUT  suspended on input: the reference's NeedMore
+ *                PZG_DEC_OUT_FULL    suspended on room: call again with in_base + in_used[j] onward
+ *                PZG_OK              the stream has ended: Done (trailing input is left unconsumed)
+ *                PZG_E_*             DecompError; detail[2j..] as for pzg_decompress_many
+ *   in_used[j]   input bytes the decoder is done with (it remembers a partly consumed byte itself)
+ *   chunks[j]    how many 32,768-byte chunks the reference has published up to this point (cumulative): moveWindow
+ *                runs after every match and block end and publishes one when 64 KiB are buffered
+ *                (OutputWindow.hs:45-54); the host mirror cuts the delivered bytes into exactly those Chunks, and at
+ *                PZG_OK publishes the remainder as the last one (finalize, Monad.hs:349-353).
+ * Host pointers only.  Nothing is re-decoded: a feed costs what its new input costs.
+ */
+typedef struct pzg_decoder pzg_decoder;
+int  pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out);
+void pzg_decoder_destroy(pzg_decoder *dec);
+int  pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m);  /* those decoders start a new stream */
+int  pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m,
+                      const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len, const uint8_t *final_in,
+                      uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap,
+                      uint64_t *out_len, int32_t *state, uint32_t *detail, uint64_t *in_used,
+                      uint32_t *chunks, uint32_t *adler);
 
 /* decompress: the single-stream form (n = 1, host pointers). */
 int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len,

@@ -129,3 +129,46 @@ def compute_code_values(pairs):
     os_, ol, oc = (C.c_int * 512)(), (C.c_int * 512)(), (C.c_int * 512)()
     m = lib().pzo_compute_code_values(syms, lens, n, os_, ol, oc)
     return [(os_[i], ol[i], oc[i]) for i in range(m)]
+
+
+EV_NEED_MORE, EV_CHUNK, EV_DONE, EV_ERROR = 1, 2, 3, 4
+
+
+def trace(pieces, out_cap: int = None):
+    """decompressIncremental driven one piece per NeedMore (Deflate.hs:30-48): the list of events
+    ("NeedMore",) / ("Chunk", length) / ("Done",) / ("DecompError", status), the Result and the bytes."""
+    L = lib()
+    L.pzo_trace.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                            C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(Result)]
+    L.pzo_trace.restype = C.c_int
+    flat = b"".join(pieces)
+    offs = [0]
+    for c in pieces:
+        offs.append(offs[-1] + len(c))
+    if out_cap is None:
+        out_cap = max(1 << 16, len(flat) * 1100 + 64)
+    out = C.create_string_buffer(max(out_cap, 1))
+    arr = (C.c_uint64 * len(offs))(*offs)
+    cap = 4 * len(pieces) + 64 + (len(flat) * 1100) // 32768
+    et = (C.c_int32 * cap)()
+    ev = (C.c_uint32 * cap)()
+    n = C.c_uint32(0)
+    r = Result()
+    L.pzo_trace(flat, arr, len(pieces), out, out_cap, et, ev, cap, C.byref(n), C.byref(r))
+    assert n.value <= cap
+    names = {EV_NEED_MORE: "NeedMore", EV_CHUNK: "Chunk", EV_DONE: "Done", EV_ERROR: "DecompError"}
+    events = [(names[et[k]],) if et[k] in (EV_NEED_MORE, EV_DONE) else (names[et[k]], int(ev[k])) for k in range(n.value)]
+    return events, r, out.raw[: min(r.out_len, out_cap)]
+
+
+def decompress_dict(data: bytes, zdict: bytes, out_cap: int = None):
+    """EXTENSION: with the preset dictionary (RFC 1950 FDICT) installed; pinned against zlib.decompressobj(zdict=...)."""
+    L = lib()
+    L.pzo_decompress_dict.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(Result)]
+    L.pzo_decompress_dict.restype = C.c_int
+    if out_cap is None:
+        out_cap = max(1 << 16, len(data) * 1100 + 64)
+    out = C.create_string_buffer(max(out_cap, 1))
+    r = Result()
+    L.pzo_decompress_dict(data, len(data), zdict, len(zdict), out, out_cap, C.byref(r))
+    return r, out.raw[: min(r.out_len, out_cap)]

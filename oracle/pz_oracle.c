@@ -164,6 +164,13 @@ typedef struct {
     uint32_t flags;
     pzo_result *res;
     jmp_buf jb;
+    /* event trace of the incremental protocol (pzo_trace): NeedMore / Chunk / Done / DecompError, Monad.hs:163-167 */
+    int32_t *ev_type;
+    uint32_t *ev_val;
+    uint32_t ev_cap, ev_n;
+    /* extension (PZO dictionary): preset dictionary = history in front of the output */
+    const uint8_t *dict;
+    uint64_t dict_len;
     htree fixed_lit, fixed_dist, code_tree, lit_tree, dist_tree;
 } dstate;
 
@@ -177,10 +184,20 @@ static void raise_err(dstate *s, int status, uint32_t d0, uint32_t d1, const cha
     longjmp(s->jb, 1);
 }
 
+static void trace_event(dstate *s, int32_t type, uint32_t val)
+{
+    if (s->ev_type && s->ev_n < s->ev_cap) {
+        s->ev_type[s->ev_n] = type;
+        s->ev_val[s->ev_n] = val;
+    }
+    if (s->ev_type) s->ev_n++;
+}
+
 /* Monad.hs:185-197 getNextChunk/loadChunk driven by Zlib.hs:38-42 */
 static void get_next_chunk(dstate *s)
 {
     for (;;) {
+        trace_event(s, PZO_EV_NEED_MORE, 0); /* Monad.hs:186 / :194: the decoder hands NeedMore back */
         if (s->chunk_next >= s->nchunks)
             raise_err(s, PZO_E_TRUNCATED, 0, 0,
                       "Decompression error: Ran out of data mid-decompression 2.");
@@ -355,7 +372,10 @@ static void emit_byte(dstate *s, uint8_t v)
 /* Monad.hs:335-347 moveWindow -> OutputWindow.hs:45-54 emitExcess: ONE 32 KiB piece per call */
 static void move_window(dstate *s)
 {
-    if (s->ow_next >= 2u * 32768u) s->ow_next -= 32768u;
+    if (s->ow_next >= 2u * 32768u) {
+        s->ow_next -= 32768u;
+        trace_event(s, PZO_EV_CHUNK, 32768u); /* Monad.hs:346 publish builtChunk */
+    }
 }
 
 /* Monad.hs:324-333 emitPastChunk -> OutputWindow.hs:82-101 addOldChunk/copyChunked:
@@ -363,7 +383,7 @@ static void move_window(dstate *s)
 static void emit_past_chunk(dstate *s, uint32_t dist, uint32_t len)
 {
     uint32_t a, b, i;
-    if ((uint64_t)dist > s->total) { /* MV.slice (next - dist) ... with next - dist < 0 */
+    if ((uint64_t)dist > s->total + s->dict_len) { /* MV.slice (next - dist) ... with next - dist < 0 */
         char m[160];
         snprintf(m, sizeof m,
                  "(reference throws) back-reference distance %u exceeds the %llu bytes produced",
@@ -374,7 +394,8 @@ static void emit_past_chunk(dstate *s, uint32_t dist, uint32_t len)
     a = s->a;
     b = s->b;
     for (i = 0; i < len; i++) {
-        uint8_t v = s->win[(s->total - dist) & 65535u];
+        uint8_t v = (uint64_t)dist > s->total ? s->dict[s->dict_len - (dist - s->total)] /* extension: into the preset dictionary */
+                                              : s->win[(s->total - dist) & 65535u];
         put_byte(s, v);
         a += v; /* Adler over the copied bytes, Monad.hs:331; len <= 258 < 5552 */
         b += a;
@@ -631,7 +652,7 @@ static void build_fixed(dstate *s)
 
 /* Zlib.hs:53-69 inflateWithHeaders + Deflate.hs:39-63 inflate/checkChecksum */
 /* RFC 1952 member: header (2.3), deflate, CRC32 + ISIZE little-endian.  Extension, see PZO_F_GZIP. */
-static void inflate_gzip_member(dstate *s)
+static void inflate_gzip_member_header(dstate *s)
 {
     uint32_t hreg = 0xffffffffu, id1, id2, cm, flg, i;
     char m[128];
@@ -664,28 +685,69 @@ static void inflate_gzip_member(dstate *s)
         }
     }
 #undef GZ_NEXT
-    build_fixed(s);
+}
+
+/* x^(8 n) mod P in the reflected representation, by square and multiply: the shift that crc32_combine applies */
+static uint32_t gf2_mul(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    int i;
+    for (i = 0; i < 32; i++) {
+        if ((a >> (31 - i)) & 1u) p ^= b;
+        b = (b >> 1) ^ (0xedb88320u & (0u - (b & 1u)));
+    }
+    return p;
+}
+static uint32_t crc32_append(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
+{
+    uint32_t pw = 0x80000000u, sq = 0x00800000u;
+    for (; len_b; len_b >>= 1) {
+        if (len_b & 1u) pw = gf2_mul(pw, sq);
+        sq = gf2_mul(sq, sq);
+    }
+    return gf2_mul(crc_a, pw) ^ crc_b;
+}
+
+/* RFC 1952 2.2: a gzip file is a series of members, decoded one after the other into one output (extension; pinned
+ * against Python's gzip.decompress for valid files).  Every member's ISIZE is checked as it ends; the members'
+ * CRC-32s are combined into the CRC the whole output must have, checked when decoding stops (and before a length
+ * mismatch is reported, as zlib orders the two checks). */
+static void inflate_gzip_members(dstate *s)
+{
+    uint32_t expect = 0;
+    uint64_t mstart = 0;
+    char m[128];
     s->crc = 0xffffffffu;
     for (;;) {
-        int is_final = inflate_block(s);
-        move_window(s);
-        if (is_final) break;
-    }
-    {
-        uint32_t ours = ~s->crc, theirs, isize;
+        uint32_t theirs, isize;
+        int bad_len;
+        inflate_gzip_member_header(s);
+        build_fixed(s);
+        for (;;) {
+            int is_final = inflate_block(s);
+            move_window(s);
+            if (is_final) break;
+        }
         advance_to_byte(s);
         theirs = next_word16(s);
         theirs |= next_word16(s) << 16;
         isize = next_word16(s);
         isize |= next_word16(s) << 16;
-        if (theirs != ours) {
-            snprintf(m, sizeof m, "Checksum error: checksum mismatch: %x != %x", theirs, ours);
-            raise_err(s, PZO_E_CHECKSUM, theirs, ours, m);
+        expect = crc32_append(expect, theirs, s->total - mstart);
+        bad_len = isize != (uint32_t)(s->total - mstart);
+        if (bad_len || s->p + 2 > s->pend || s->p[0] != 0x1f || s->p[1] != 0x8b) { /* the last member (or a broken one) */
+            uint32_t ours = ~s->crc;
+            if (expect != ours) {
+                snprintf(m, sizeof m, "Checksum error: checksum mismatch: %x != %x", expect, ours);
+                raise_err(s, PZO_E_CHECKSUM, expect, ours, m);
+            }
+            if (bad_len) {
+                snprintf(m, sizeof m, "Checksum error: gzip: length mismatch: %u != %u", isize, (uint32_t)(s->total - mstart));
+                raise_err(s, PZO_E_GZIP_ISIZE, isize, (uint32_t)(s->total - mstart), m);
+            }
+            return;
         }
-        if (isize != (uint32_t)s->total) {
-            snprintf(m, sizeof m, "Checksum error: gzip: length mismatch: %u != %u", isize, (uint32_t)s->total);
-            raise_err(s, PZO_E_GZIP_ISIZE, isize, (uint32_t)s->total, m);
-        }
+        mstart = s->total;
     }
 }
 
@@ -707,9 +769,21 @@ static void inflate_with_headers(dstate *s)
         raise_err(s, PZO_E_HDR_WINDOW, cinfo, 0, m);
     }
     if (flg & 0x20) { /* :68 skip DICTID, no dictionary is installed */
+        uint32_t id = 0;
         int i;
-        s->res->quirks |= PZO_QUIRK_FDICT_SKIPPED;
-        for (i = 0; i < 4; i++) (void)next_byte(s);
+        for (i = 0; i < 4; i++) id = (id << 8) | next_byte(s);
+        if (s->dict_len == 0) {
+            s->res->quirks |= PZO_QUIRK_FDICT_SKIPPED;
+        } else { /* EXTENSION (not in the reference): RFC 1950 2.2 -- DICTID is the Adler-32 of the dictionary */
+            uint32_t ours = pzo_adler32(1, s->dict, s->dict_len);
+            if (id != ours) {
+                snprintf(m, sizeof m, "Header error: preset dictionary mismatch: %x != %x", id, ours);
+                s->dict_len = 0;
+                raise_err(s, PZO_E_DICT, id, ours, m);
+            }
+        }
+    } else {
+        s->dict_len = 0; /* a dictionary is history only for a stream that asks for one */
     }
     build_fixed(s); /* Deflate.hs:41-42 */
     for (;;) {      /* Deflate.hs:45-50 go */
@@ -729,12 +803,20 @@ static void inflate_with_headers(dstate *s)
     }
 }
 
-int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t n_chunks,
-                          uint8_t *out, uint64_t out_cap, uint32_t flags, pzo_result *res)
+static int decompress_core(const uint8_t *in, const uint64_t *chunk_off, uint32_t n_chunks,
+                           uint8_t *out, uint64_t out_cap, uint32_t flags, pzo_result *res,
+                           const uint8_t *dict, uint64_t dict_len,
+                           int32_t *ev_type, uint32_t *ev_val, uint32_t ev_cap, uint32_t *n_events)
 {
     static __thread dstate st; /* large (tries + window): keep it off the stack */
     dstate *s = &st;
     memset(res, 0, sizeof *res);
+    s->ev_type = ev_type;
+    s->ev_val = ev_val;
+    s->ev_cap = ev_cap;
+    s->ev_n = 0;
+    s->dict = dict;
+    s->dict_len = dict ? dict_len : 0;
     s->base = in;
     s->coff = chunk_off;
     s->nchunks = n_chunks;
@@ -752,7 +834,7 @@ int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t
     s->res = res;
     s->crc = 0xffffffffu;
     if (setjmp(s->jb) == 0) {
-        if (flags & PZO_F_GZIP) inflate_gzip_member(s);
+        if (flags & PZO_F_GZIP) inflate_gzip_members(s);
         else inflate_with_headers(s);
         /* Zlib.hs:46-49: Done with chunks left over is an error, Done with none is Right */
         if (s->chunk_next < s->nchunks) {
@@ -764,10 +846,43 @@ int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t
             snprintf(res->message, sizeof res->message, "(not a reference outcome) output buffer too small");
         }
     }
+    /* the incremental protocol's last events: finalize (Monad.hs:349-353) publishes what is left in the window, then
+     * Done; or the DecompError.  ("Finished with data remaining." belongs to decompress, Zlib.hs:46-49, not to it.) */
+    if (res->status == PZO_OK || res->status == PZO_E_DATA_REMAINING || res->status == PZO_E_OUT_TOO_SMALL) {
+        trace_event(s, PZO_EV_CHUNK, (uint32_t)s->ow_next);
+        trace_event(s, PZO_EV_DONE, 0);
+    } else if (res->status != PZO_E_TRUNCATED) {
+        trace_event(s, PZO_EV_ERROR, (uint32_t)res->status);
+    }
+    if (n_events) *n_events = s->ev_n;
     res->adler = (flags & PZO_F_GZIP) ? ~s->crc : ((s->b << 16) | s->a);
     res->out_len = s->total;
     res->in_used = (uint64_t)(s->p - in);
     return res->status;
+}
+
+int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t n_chunks,
+                          uint8_t *out, uint64_t out_cap, uint32_t flags, pzo_result *res)
+{
+    return decompress_core(in, chunk_off, n_chunks, out, out_cap, flags, res, NULL, 0, NULL, NULL, 0, NULL);
+}
+
+/* decompressIncremental (Zlib.hs, Monad.hs:163-197) driven the way Deflate.hs:30-48 drives it, one input piece per
+ * NeedMore: the sequence of ZlibDecoder constructors it goes through.  ev_val = chunk length / status. */
+int pzo_trace(const uint8_t *in, const uint64_t *chunk_off, uint32_t n_chunks, uint8_t *out, uint64_t out_cap,
+              int32_t *ev_type, uint32_t *ev_val, uint32_t ev_cap, uint32_t *n_events, pzo_result *res)
+{
+    return decompress_core(in, chunk_off, n_chunks, out, out_cap, 0, res, NULL, 0, ev_type, ev_val, ev_cap, n_events);
+}
+
+/* EXTENSION (the reference skips DICTID, Zlib.hs:68): one chunk, with the preset dictionary the stream was made with */
+int pzo_decompress_dict(const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint64_t dict_len,
+                        uint8_t *out, uint64_t out_cap, pzo_result *res)
+{
+    uint64_t off[2];
+    off[0] = 0;
+    off[1] = in_len;
+    return decompress_core(in, off, in_len ? 1u : 0u, out, out_cap, 0, res, dict, dict_len, NULL, NULL, 0, NULL);
 }
 
 int pzo_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_cap, pzo_result *res)

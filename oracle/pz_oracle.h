@@ -55,6 +55,7 @@ enum {
      * a TODO).  Restated from the RFC, pinned against system zlib (wbits = 31), not
      * against pure-zlib. */
     PZO_E_GZIP_HEADER = 18,     /* detail0: 1 magic, 2 method != 8, 3 reserved FLG bits, 4 header CRC16 */
+    PZO_E_DICT = 20,            /* EXTENSION (pzo_decompress_dict): DICTID (detail0) is not the Adler-32 of the dictionary supplied (detail1) */
     PZO_E_GZIP_ISIZE = 19       /* detail0 = ISIZE in the trailer, detail1 = bytes produced mod 2^32 (CRC mismatch is PZO_E_CHECKSUM) */
 };
 
@@ -99,6 +100,21 @@ int pzo_decompress(const uint8_t *in, uint64_t in_len,
  * mapping of Zlib.hs:37-51 including "Finished with data remaining.". */
 int pzo_decompress_chunks(const uint8_t *in, const uint64_t *chunk_off, uint32_t n_chunks,
                           uint8_t *out, uint64_t out_cap, uint32_t flags, pzo_result *res);
+
+/* The ZlibDecoder constructors (Monad.hs:163-167) as trace events */
+enum { PZO_EV_NEED_MORE = 1, PZO_EV_CHUNK = 2, PZO_EV_DONE = 3, PZO_EV_ERROR = 4 };
+
+/* decompressIncremental driven one input piece per NeedMore (Deflate.hs:30-48): the events it goes through.
+ * ev_type/ev_val[0..ev_cap) receive the first events, *n_events their total number; ev_val = chunk length / status.
+ * When the pieces run out the trace ends with the NeedMore nothing answers (status PZO_E_TRUNCATED). */
+int pzo_trace(const uint8_t *in, const uint64_t *chunk_off, uint32_t n_chunks, uint8_t *out, uint64_t out_cap,
+              int32_t *ev_type, uint32_t *ev_val, uint32_t ev_cap, uint32_t *n_events, pzo_result *res);
+
+/* EXTENSION: decompress with a preset dictionary (RFC 1950 FDICT).  The reference skips DICTID and decodes with an
+ * empty history (Zlib.hs:68) -- that is what pzo_decompress does; this entry point installs the dictionary instead,
+ * pinned against system zlib (zlib.decompressobj(zdict=...)). */
+int pzo_decompress_dict(const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint64_t dict_len,
+                        uint8_t *out, uint64_t out_cap, pzo_result *res);
 
 /* Adler32.hs:19-57.  `adler` is a finalized value ((b<<16)|a); pass 1 to start. */
 uint32_t pzo_adler32(uint32_t adler, const uint8_t *buf, uint64_t len);

@@ -29,6 +29,9 @@ E_OUT_TOO_SMALL = 14
 E_DATA_REMAINING = 15
 E_GZIP_HEADER = 18  # PZG_GZIP only (extension)
 E_GZIP_ISIZE = 19
+E_DICT = 20  # pzg_decompress_many_dict only (extension)
+DEC_NEED_INPUT = 101  # pzg_decoder_feed: NeedMore
+DEC_OUT_FULL = 102    # pzg_decoder_feed: this call's output room is used up
 
 DEVICE_PTRS = 1
 ASYNC = 2
@@ -39,7 +42,8 @@ DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares
 SYMBOLS = [
-    "pzg_init", "pzg_init_mask", "pzg_device_count", "pzg_adler32_many", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
+    "pzg_init", "pzg_init_mask", "pzg_device_count", "pzg_adler32_many", "pzg_decompress_many_dict",
+    "pzg_decoder_create", "pzg_decoder_destroy", "pzg_decoder_reset", "pzg_decoder_feed", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
     "pzg_adler32", "pzg_error_message", "pzg_last_kernel_ms", "pzg_strerror", "pzg_last_error", "pzg_version",
 ]
 
@@ -83,6 +87,17 @@ def lib():
     L.pzg_decompress_many.argtypes = [C.c_void_p, vp, u64p, u64p, vp, u64p, u64p, u64p, i32p, u32p, u64p, u32p,
                                       C.c_uint32, C.c_uint32]
     L.pzg_decompress_many.restype = C.c_int
+    L.pzg_decompress_many_dict.argtypes = [C.c_void_p, vp, u64p, u64p, vp, u64p, u64p, vp, u64p, u64p, u64p, i32p, u32p, u64p, u32p,
+                                           C.c_uint32, C.c_uint32]
+    L.pzg_decompress_many_dict.restype = C.c_int
+    L.pzg_decoder_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.pzg_decoder_create.restype = C.c_int
+    L.pzg_decoder_destroy.argtypes = [C.c_void_p]
+    L.pzg_decoder_destroy.restype = None
+    L.pzg_decoder_reset.argtypes = [C.c_void_p, u32p, C.c_uint32]
+    L.pzg_decoder_reset.restype = C.c_int
+    L.pzg_decoder_feed.argtypes = [C.c_void_p, u32p, C.c_uint32, vp, u64p, u64p, vp, vp, u64p, u64p, u64p, i32p, u32p, u64p, u32p, u32p]
+    L.pzg_decoder_feed.restype = C.c_int
     L.pzg_decompress.argtypes = [C.c_void_p, vp, C.c_uint64, vp, C.c_uint64, u64p, i32p, u32p, u64p]
     L.pzg_decompress.restype = C.c_int
     L.pzg_adler32.argtypes = [C.c_void_p, vp, C.c_uint64, C.c_uint32, u32p, C.c_uint32]

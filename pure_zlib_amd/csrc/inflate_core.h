@@ -62,6 +62,9 @@ enum : int32_t {
     ST_OUT_TOO_SMALL = 14,
     ST_GZIP_HEADER = 18,  // extension (RFC 1952): detail0 = 1 magic, 2 method, 3 reserved flag bits, 4 header CRC16
     ST_GZIP_ISIZE = 19,   // extension: detail0 = ISIZE in the trailer, detail1 = bytes produced mod 2^32
+    ST_DICT = 20,         // extension (PZG_FDICT): detail0 = DICTID of the stream, detail1 = Adler-32 of the dictionary supplied
+    ST_NEED_INPUT = 101,  // resumable decoder: every complete token of the input so far has been decoded; more input is needed
+    ST_OUT_FULL = 102,    // resumable decoder: the output room of this call is used up; call again with what is left of the input
     ST_RETRY_FULL_RING = 100  // internal: a small-ring launch met an output larger than its capacity; the 32 KiB ring kernel redoes the stream
 };
 
@@ -193,9 +196,53 @@ struct StreamResult {
     int32_t status;
     uint32_t detail0, detail1;
     uint32_t adler;
+    uint32_t gz_crc;   // gzip only: the CRC-32 the output must have according to the members' trailers
     uint64_t out_len;
     uint64_t in_used;
 };
+
+// ---- resumable decoding (decompressIncremental, Monad.hs:163-197): what a suspended decoder keeps in HBM -------
+// The scalars below, the token queue, and behind them the wave's whole LDS image (tables + the 32 KiB ring: the
+// resumable kernel is the RING_BITS = 15 instance, so the window needs nothing but LDS).
+enum : uint32_t { PH_HEADER = 0, PH_BLOCK = 1, PH_STORED = 2, PH_TOKENS = 3, PH_TRAILER = 4, PH_DONE = 5 };
+struct ResumeState {
+    uint32_t phase;        // where decoding resumes (a fresh decoder is all zeros)
+    uint32_t bfinal;       // the block being decoded is the last one
+    uint32_t stored_left;  // PH_STORED: bytes of the stored block still to copy
+    uint32_t deferred;     // PH_TOKENS: 0, or the outcome (end of block / an error status) met while the queue was not yet drained
+    uint32_t qn;           // tokens waiting in QT
+    uint32_t bit_skip;     // bits of the first byte of the next input that are already consumed
+    uint32_t ow, chunks;   // the reference's window fill (OutputWindow.hs owNext) and the 32 KiB chunks it has published so far
+    uint64_t op;           // bytes produced so far
+    uint32_t adler_a, adler_b, lit_e15, dist_e15, lit_n, dist_n, use_sub, lit_sub_used;
+    int32_t status;        // a terminal status once the decoder has failed (PH_DONE)
+    uint32_t detail0, detail1, pad;
+    uint64_t in_total;     // input bytes consumed by the earlier calls (positions in error details count from the stream start)
+    uint32_t QT[64];
+};
+
+// CRC-32 (reflected, poly 0xedb88320) as a polynomial over GF(2): a * b mod P, and the CRC of "A followed by n more
+// bytes that are B" from the two finalized CRCs (zlib's crc32_combine): shift A by 8n bits, add B.
+PZG_FN uint32_t gf2_mul(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+#pragma nounroll
+    for (int i = 0; i < 32; ++i) {
+        p ^= b & (0u - ((a >> (31 - i)) & 1u));
+        b = (b >> 1) ^ (0xedb88320u & (0u - (b & 1u)));
+    }
+    return p;
+}
+PZG_FN uint32_t crc32_append(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
+{
+    uint32_t pw = 0x80000000u, sq = 0x00800000u;  // x^0, x^8
+#pragma nounroll
+    for (uint64_t e = len_b; e != 0; e >>= 1) {
+        if (e & 1u) pw = gf2_mul(pw, sq);
+        sq = gf2_mul(sq, sq);
+    }
+    return gf2_mul(crc_a, pw) ^ crc_b;
+}
 
 // ---- Monad.hs:203-307: the bit reader ---------------------------------------------------------
 // The compressed stream is read as aligned dwords, 64 at a time: lane l of `cur` holds dword
@@ -350,7 +397,8 @@ struct BitReader {
 
 // ---- decoder state (all wave-uniform) -----------------------------------------------------------
 // GZIP: the streams are RFC 1952 members (an extension; its own kernel instances, so the zlib ones carry none of it)
-template <int RING_BITS, bool GZIP = false>
+// RES: the resumable instance (decompressIncremental): suspends when the input or the output room runs out
+template <int RING_BITS, bool GZIP = false, bool RES = false>
 struct Decoder {
     static constexpr uint32_t RING = 1u << RING_BITS;
     static constexpr uint32_t RMASK = RING - 1u;
@@ -380,6 +428,16 @@ struct Decoder {
     uint32_t pend_pos;          // those bytes belong at ring position pend_pos + 64 * pass + lane
     LaneVec<uint8_t> pendF0, pendF1;   // the far bytes (valid in the lanes of pend_m0 / pend_m1); bytes, so that nothing
                                        // (no zero-extension either) touches the loaded registers before complete_pending()
+    // extension (PZG_FDICT): a preset dictionary primes the history; only the RING_BITS = 15 instance decodes with one
+    const uint8_t *dict;
+    uint32_t dict_len;          // 0: none -- a stream with FDICT set then decodes as the reference does (DICTID skipped)
+    uint32_t gz_expect;         // gzip: CRC-32 of the whole output according to the member trailers read so far
+    uint32_t hist_extra;        // bytes of history in front of the output (min(dict_len, 32768) once the dictionary is installed)
+    // resumable instance only
+    uint32_t res_final;         // no more input will follow: running out of it is an error, not a suspension
+    uint32_t phase, bfinal_cur, stored_left, deferred, ow, chunks;
+    uint64_t susp_pos;          // stream bit position (relative to this call's input) at which the next call resumes
+    uint64_t in_total_bits;     // 8 * the input bytes consumed by earlier calls
     uint32_t qn;                // tokens waiting in QT (lanes 0..qn-1), see window_append()
     LaneVec<uint32_t> QT;
 #if defined(PZG_PROFILE)
@@ -415,6 +473,7 @@ struct Decoder {
         pend_m0 = uni64(pend_m0);
         pend_m1 = uni64(pend_m1);
         pend_pos = uni(pend_pos);
+        hist_extra = uni(hist_extra);
         qn = uni(qn);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
@@ -446,7 +505,11 @@ struct Decoder {
         const uint32_t nvec = (n + 15u) >> 4;
         const uint32_t lane = lane_id();
         const bool out_al = (((uintptr_t)out) & 15u) == 0u;
-        uint32_t a_l = 0, w_l = 0, u_l = 0;
+#if PZG_DEVICE_PASS
+        uint32_t a_l = 0, w_l = 0, u_l = 0;  // a lane sees at most RING / 1024 vectors per flush: no overflow
+#else
+        uint64_t a_l = 0, w_l = 0, u_l = 0;  // (the one-lane host model walks every vector itself)
+#endif
 #pragma nounroll
         for (uint32_t it = 0; it * PZG_WAVE < nvec; ++it) {
             const uint32_t j = it * PZG_WAVE + lane;
@@ -498,7 +561,7 @@ struct Decoder {
         int64_t bl = (int64_t)((int64_t)n - 16 * (int64_t)lane - 16) * (int64_t)a_l + (int64_t)w_l -
                      (int64_t)(16u * PZG_WAVE) * (int64_t)u_l;
         uint32_t bl_mod = (uint32_t)((uint64_t)bl % ADLER_MOD);
-        uint32_t sum_a = wave_sum(a_l);
+        uint32_t sum_a = wave_sum((uint32_t)(a_l % ADLER_MOD));
         uint32_t sum_b = wave_sum(bl_mod);
         // Adler32.hs:22-27 in block form: A' = A + sum d ; B' = B + n*A + sum (n - pos) d
         uint64_t nb = (uint64_t)adler_b + (uint64_t)(n % ADLER_MOD) * adler_a + sum_b;
@@ -1275,13 +1338,43 @@ struct Decoder {
         }
     }
 
+    // Resumable instance: the reference publishes its output in 32 KiB chunks -- moveWindow (Monad.hs:338-347) runs after
+    // every match and at every block end and hands out ONE chunk when the window holds 64 KiB or more
+    // (OutputWindow.hs:45-54).  `ow` follows the window fill and `chunks` the count, token by token where it matters, so
+    // that the host publishes exactly the chunks the reference has published when the input runs out.
+    PZG_FN void account_tokens(uint32_t run, uint32_t v, bool single_match)
+    {
+        if (single_match) {
+            ow += run;
+            move_window_check();
+            return;
+        }
+        if (ow + run < 65536u) {  // no check in this segment can fire
+            ow += run;
+            return;
+        }
+        for (uint32_t t = 0; t < v; ++t) {  // (the queue has not moved up yet when emit_segment calls this)
+            const uint32_t tk = lane_get(QT, t);
+            ow += (tk >> 16) & 511u;
+            if ((int32_t)tk < 0) move_window_check();
+        }
+    }
+    PZG_FN void move_window_check()
+    {
+        if (ow >= 65536u) {
+            ow -= 32768u;
+            chunks += 1u;
+        }
+    }
     PZG_FN int emit_segment()
     {
         PZG_T0(t_a);
         complete_pending();  // the previous segment's bytes must all be in the ring from here on
         PZG_ACCW(8, t_a);
+        if (RES && op + 512u > cap) return ST_OUT_FULL;  // (resumable: never produce past this call's output room)
         PZG_T0(t_b);
-        const uint32_t hist = (op >> 20) ? 0x100000u : (uint32_t)op;  // dist <= 32768: a clamp is enough (scalar shift + test)
+        // bytes of history a distance may reach back over; dist <= 32768, so a clamp is enough (scalar shift + test)
+        const uint32_t hist = (op >> 20) ? 0x100000u : (uint32_t)op + (RING_BITS == 15 ? hist_extra : 0u);
         const uint32_t op32 = (uint32_t)op;
         LaneVec<uint32_t> INCL, START;
         LaneVec<bool> STOP;
@@ -1302,13 +1395,14 @@ struct Decoder {
         PZG_ACCW(9, t_b);
         if (v == 0u) {
             const uint32_t tk = lane_get(QT, 0u), dist = tk & 0xffffu, len = (tk >> 16) & 511u;
-            if ((uint64_t)dist > op) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
+            if ((uint64_t)dist > op + (RING_BITS == 15 ? hist_extra : 0u)) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             prof[14] += 1;
 #endif
             copy_match(dist, len);
             maybe_flush();
             v = 1u;
+            if (RES) account_tokens(len, 1u, true);
         } else {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             prof[13] += 1;
@@ -1361,6 +1455,7 @@ struct Decoder {
             pend_m1 = farm1;
             pend_pos = op32;
             op += run;
+            if (RES) account_tokens(run, v, false);
             PZG_ACC(11, t_d);
         }
         // the queue moves up by v tokens
@@ -1561,9 +1656,11 @@ struct Decoder {
     }
 
     // ---- Zlib.hs:53-69 inflateWithHeaders + Deflate.hs:39-63 inflate ---------------------------------
-    PZG_FN void run(const uint8_t *in_, uint64_t in_len_, uint8_t *out_, uint64_t cap_, StreamResult *res)
+    PZG_FN void run(const uint8_t *in_, uint64_t in_len_, uint8_t *out_, uint64_t cap_, StreamResult *res, const uint8_t *dict_ = nullptr,
+                    uint32_t dict_len_ = 0)
     {
-
+        dict = dict_;
+        dict_len = dict_len_;
         in = in_;
         in_len = in_len_;
         out = out_;
@@ -1582,6 +1679,12 @@ struct Decoder {
         status = ST_OK;
         detail0 = detail1 = 0;
         in_byte0 = 0;
+        hist_extra = 0;
+        gz_expect = 0;
+        res_final = 1;
+        phase = bfinal_cur = stored_left = deferred = ow = chunks = 0;
+        susp_pos = 0;
+        in_total_bits = 0;
 #if PZG_DEVICE_PASS && PZG_DMA_PREFETCH
         br.pf = L.pf;
 #endif
@@ -1596,16 +1699,17 @@ struct Decoder {
         uint64_t used_bits = stream_bit_pos();
         uint64_t used = (used_bits + 7u) >> 3;
         if (used > in_len) used = in_len;
-        if (HYBRID && op > cap && (status == ST_OK || status == ST_CHECKSUM)) {
+        if (HYBRID && op > cap && (status == ST_OK || status == ST_CHECKSUM || status == ST_GZIP_ISIZE)) {
             // bytes past the capacity were never stored, so far reads of them (and the checksum) are not
             // to be trusted: the 32 KiB-ring kernel, which needs nothing but LDS, redoes this stream
             status = ST_RETRY_FULL_RING;
         }
-        if (status == ST_OK && op > cap) status = ST_OUT_TOO_SMALL;
+        if ((status == ST_OK || (GZIP && status == ST_GZIP_ISIZE)) && op > cap) status = ST_OUT_TOO_SMALL;  // (gzip: nothing stored to check the CRC of)
         res->status = status;
         res->detail0 = detail0;
         res->detail1 = detail1;
         res->adler = (adler_b << 16) | adler_a;
+        res->gz_crc = gz_expect;
         res->out_len = op;
         res->in_used = used;
     }
@@ -1660,30 +1764,126 @@ struct Decoder {
         return ST_OK;
     }
 
-    PZG_FN int decode()
+    // Adler-32 of the preset dictionary (PZG_FDICT), 64 bytes per step: A += sum d ; B += 64 A_before + sum (64 - j) d_j
+    PZG_FN uint32_t dict_adler()
     {
-        if (GZIP) {
-            if (int st = gzip_header()) return st;
-            return blocks_and_trailer();
+        uint32_t a = 1, bsum = 0;
+        const uint32_t lane = lane_id();
+#pragma nounroll
+        for (uint32_t k0 = 0; k0 < dict_len; k0 += 64u) {
+            const uint32_t n = dict_len - k0 < 64u ? dict_len - k0 : 64u;
+            uint32_t sa = 0, sb = 0;
+#if PZG_DEVICE_PASS
+            const uint32_t v = lane < n ? dict[k0 + lane] : 0u;
+            sa = wave_sum(v);
+            sb = wave_sum((n - lane) * v);  // (lanes >= n hold 0)
+#else
+            for (uint32_t j = 0; j < n; ++j) {
+                sa += dict[k0 + j];
+                sb += (n - j) * dict[k0 + j];
+            }
+            (void)lane;
+#endif
+            bsum = (uint32_t)(((uint64_t)bsum + (uint64_t)n * a + sb) % ADLER_MOD);
+            a = (a + sa) % ADLER_MOD;
         }
-        // Zlib.hs:55-67: CMF, FLG; FCHECK, then CM, then CINFO
+        return (bsum << 16) | a;
+    }
+    // the last min(dict_len, 32768) dictionary bytes become the history in front of the output (ring positions -1, -2, ...)
+    PZG_FN void install_dictionary()
+    {
+        const uint32_t lane = lane_id();
+        const uint32_t use = dict_len < 32768u ? dict_len : 32768u;
+#pragma nounroll
+        for (uint32_t k0 = 0; k0 < use; k0 += PZG_WAVE) {
+            const uint32_t k = k0 + lane;  // byte `k + 1` positions before the output start
+            const uint8_t v = dict[dict_len - 1u - (k < use ? k : use - 1u)];
+            sel_store(k < use, &L.ring[(0u - 1u - k) & RMASK], v, lane);
+        }
+        hist_extra = use;
+        wave_sync();
+    }
+
+    // Zlib.hs:55-68: CMF, FLG; FCHECK, then CM, then CINFO; FDICT
+    PZG_FN int zlib_header()
+    {
         if (br.avail() < 16) return fail(ST_TRUNCATED, 0, 0);
         const uint32_t hw = br.peek32();
         const uint32_t cmf = hw & 0xffu, flg = (hw >> 8) & 0xffu;
+        if (RES && (flg & 0x20u) && br.avail() < 48) return fail(ST_TRUNCATED, 0, 0);  // (resumable: the header is taken whole)
         br.drop(16);
         if (((cmf << 8) | flg) % 31u != 0u) return fail(ST_HDR_FCHECK, (cmf << 8) | flg, 0);
         if ((cmf & 15u) != 8u) return fail(ST_HDR_METHOD, cmf & 15u, 0);
         if ((cmf >> 4) > 7u) return fail(ST_HDR_WINDOW, cmf >> 4, 0);
-        if (flg & 0x20u) {  // Zlib.hs:68: skip DICTID, carry on with an empty history
+        if (flg & 0x20u) {
             if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
+            const uint32_t t = br.peek32();
             br.drop(32);
+            if (dict_len != 0u) {  // extension (PZG_FDICT): a dictionary was supplied for this stream
+                if (RING_BITS != 15) return fail(ST_RETRY_FULL_RING, 0, 0);  // decoded by the 32 KiB-ring instance only
+                const uint32_t theirs = (t << 24) | ((t & 0xff00u) << 8) | ((t >> 8) & 0xff00u) | (t >> 24);
+                const uint32_t ours = dict_adler();
+                if (theirs != ours) return fail(ST_DICT, theirs, ours);
+                install_dictionary();
+            }
+            // (none supplied -- Zlib.hs:68: skip DICTID, carry on with an empty history)
         }
-        return blocks_and_trailer();
+        return ST_OK;
     }
 
-    PZG_FN int blocks_and_trailer()
+    PZG_FN int decode()
     {
-        for (;;) {  // Deflate.hs:45-50 go
+        if (GZIP) {
+            // RFC 1952 2.2: a gzip file is a series of members; they are decoded one after the other into one output.
+            // Each member's ISIZE is checked here against what it produced; the CRC-32s are folded into the CRC the
+            // whole output must have (crc32_append), which crc32_verify_kernel then checks in one pass.
+            uint64_t mstart = 0;
+            gz_expect = 0;
+            for (;;) {
+                if (int st = gzip_header()) return st;
+                if (int st = blocks()) return st;
+                br.align_to_byte();
+                if (br.avail() < 64) return fail(ST_TRUNCATED, 0, 0);
+                const uint32_t crc = br.peek32();
+                br.drop(32);
+                const uint32_t isize = br.peek32();
+                br.drop(32);
+                const uint64_t mlen = op - mstart;
+                gz_expect = crc32_append(gz_expect, crc, mlen);
+                // (reported unless the CRC-32 is wrong as well: crc32_verify_kernel looks at that first, as zlib does)
+                if (isize != (uint32_t)mlen) {
+                    flush_to(op);
+                    return fail(ST_GZIP_ISIZE, isize, (uint32_t)mlen);
+                }
+                mstart = op;
+                if (br.avail() < 16 || (br.peek32() & 0xffffu) != 0x8b1fu) break;  // no further member follows
+            }
+            flush_to(op);  // (once, at the very end: flushes move whole 16-byte groups, so only the last may end on an odd byte)
+            return ST_OK;
+        }
+        if (int st = zlib_header()) return st;
+        if (int st = blocks()) return st;
+        return zlib_trailer();
+    }
+
+    // Deflate.hs:52-63 checkChecksum: align, fold the rest of the window, compare big-endian
+    PZG_FN int zlib_trailer()
+    {
+        flush_to(op);
+        br.align_to_byte();
+        if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
+        const uint32_t t = br.peek32();
+        const uint32_t theirs = (t << 24) | ((t & 0xff00u) << 8) | ((t >> 8) & 0xff00u) | (t >> 24);
+        br.drop(32);
+        const uint32_t ours = (adler_b << 16) | adler_a;
+        if (theirs != ours) return fail(ST_CHECKSUM, theirs, ours);
+        return ST_OK;
+    }
+
+    // Deflate.hs:45-50 go: blocks up to and including the final one
+    PZG_FN int blocks()
+    {
+        for (;;) {
             pin_uniform();
             const uint32_t block_bit = (uint32_t)stream_bit_pos();
             if (br.avail() < 3) return fail(ST_TRUNCATED, 0, 0);
@@ -1709,26 +1909,310 @@ struct Decoder {
                 PZG_ACC(2, tt);
             }
             if (st != ST_OK) return st;
-            if (bfinal) break;
+            if (bfinal) return ST_OK;
         }
-        // Deflate.hs:52-63 checkChecksum: align, fold the rest of the window, compare big-endian
-        flush_to(op);
-        br.align_to_byte();
-        if (GZIP) {  // RFC 1952: CRC-32 then ISIZE, little-endian; crc32_verify_kernel checks both against the output
-            if (br.avail() < 64) return fail(ST_TRUNCATED, 0, 0);
-            detail0 = br.peek32();  // (a successful stream has no other use for the two detail words)
-            br.drop(32);
-            detail1 = br.peek32();
-            br.drop(32);
+    }
+
+    // ---- the resumable instance: decompressIncremental (Monad.hs:163-197, Zlib.hs decompressIncremental) -----------
+    // One call decodes as far as this call's input and output room allow and leaves the decoder in a ResumeState:
+    //   ST_NEED_INPUT  every complete element of the input has been consumed (the reference's NeedMore); the next call
+    //                  passes the unconsumed tail (from in_used on) followed by new input
+    //   ST_OUT_FULL    the output room is used up; call again with the rest of the input and fresh room
+    //   ST_OK / error  the stream has ended
+    // Running out of input inside an element (a header, a token, the trailer) rewinds to the start of that element:
+    // nothing of it has been acted upon, so re-reading it with more input behind it is the same as the reference
+    // resuming mid-element.  Stored blocks are copied as far as input and room go.
+    PZG_FN int suspend_input(uint64_t at_bit)
+    {
+        susp_pos = at_bit;
+        status = ST_OK;
+        detail0 = detail1 = 0;
+        return ST_NEED_INPUT;
+    }
+    PZG_FN bool truncated_suspends(int st) const { return st == ST_TRUNCATED && !res_final; }
+
+    // the tokens of one block: token_loop() with the two ways out that a resumable decoder adds
+    PZG_FN int token_loop_res()
+    {
+        if (deferred != 0u) susp_pos = stream_bit_pos();  // (resumed while draining: nothing of this call's input is consumed yet)
+        for (;;) {
+            int st;
+            if (deferred == 0u) {
+                const bool checked = qn < QHIGH && fill_queue();
+                if (!checked) {
+                    const int se = emit_segment();
+                    if (se == ST_OUT_FULL) {
+                        susp_pos = stream_bit_pos();
+                        return ST_OUT_FULL;
+                    }
+                    if (se) return se;
+                    continue;
+                }
+                const uint64_t tok_pos = stream_bit_pos();  // where the token about to be decoded starts
+                st = token_step_checked();
+                if (st == ST_OK) continue;
+                if (truncated_suspends(st)) {
+                    // the token is not all there yet: everything before it is decoded first, then the input is asked for
+                    status = ST_OK;
+                    susp_pos = tok_pos;
+                    st = ST_NEED_INPUT;
+                } else {
+                    susp_pos = stream_bit_pos();
+                }
+                deferred = (uint32_t)st;
+            }
+            // end of block, an error, or the input ran out: first everything that precedes it in the stream
+            while (qn != 0u) {
+                const int se = emit_segment();
+                if (se == ST_OUT_FULL) return ST_OUT_FULL;  // (deferred stays set: the next call goes on draining)
+                if (se) return se;
+            }
+            complete_pending();
+            st = (int)deferred;
+            deferred = 0u;
+            if (st == ST_NEED_INPUT) return ST_NEED_INPUT;
+            if (st != STEP_EOB) {  // the error found behind the queued tokens (its detail words were kept by fail())
+                status = st;
+                return st;
+            }
             return ST_OK;
         }
-        if (br.avail() < 32) return fail(ST_TRUNCATED, 0, 0);
-        const uint32_t t = br.peek32();
-        const uint32_t theirs = (t << 24) | ((t & 0xff00u) << 8) | ((t >> 8) & 0xff00u) | (t >> 24);
-        br.drop(32);
-        const uint32_t ours = (adler_b << 16) | adler_a;
-        if (theirs != ours) return fail(ST_CHECKSUM, theirs, ours);
-        return ST_OK;
+    }
+
+    PZG_FN int resume_decode()
+    {
+        for (;;) {
+            pin_uniform();
+            if (phase == PH_HEADER) {
+                const int st = zlib_header();
+                if (truncated_suspends(st)) return suspend_input(0);
+                if (st) return st;
+                phase = PH_BLOCK;
+            } else if (phase == PH_BLOCK) {
+                const uint64_t blk_pos = stream_bit_pos();
+                const uint32_t block_bit = (uint32_t)(in_total_bits + blk_pos);  // (from the start of the whole stream)
+                if (br.avail() < 3) {
+                    if (!res_final) return suspend_input(blk_pos);
+                    return fail(ST_TRUNCATED, 0, 0);
+                }
+                const uint32_t bh = br.peek32();
+                const uint32_t btype = (bh >> 1) & 3u;
+                bfinal_cur = bh & 1u;
+                br.drop(3);
+                if (btype == 0u) {
+                    br.align_to_byte();  // advanceToByte (Monad.hs:304-307)
+                    if (br.avail() < 32) {
+                        if (!res_final) return suspend_input(blk_pos);
+                        return fail(ST_TRUNCATED, 0, 0);
+                    }
+                    const uint32_t w = br.peek32();
+                    const uint32_t len = w & 0xffffu, nlen = w >> 16;
+                    if (len != ((~nlen) & 0xffffu)) return fail(ST_FMT_LEN_NLEN, len, nlen);
+                    br.drop(32);
+                    stored_left = len;
+                    ow += len;  // (emitBlock adds the block to the window as a whole, Deflate.hs:77)
+                    phase = PH_STORED;
+                } else if (btype == 3u) {
+                    return fail(ST_FMT_BTYPE, 3, 0);
+                } else {
+                    if (btype == 1u) {
+                        load_fixed_tables();
+                    } else {
+                        const int st = dynamic_header(block_bit);
+                        if (truncated_suspends(st)) return suspend_input(blk_pos);
+                        if (st) return st;
+                    }
+                    phase = PH_TOKENS;
+                }
+            } else if (phase == PH_STORED) {
+                // Monad.hs:265-293 nextBlock + Monad.hs:317-322 emitBlock, as far as the input and the room go
+                const uint64_t p = stream_bit_pos() >> 3;  // byte offset of the raw data in this call's input
+                uint64_t n = stored_left;
+                bool more_input = false, more_room = false;
+                if (p + n > in_len) {
+                    n = in_len - p;
+                    more_input = true;
+                }
+                if (op + n + 512u > cap) {
+                    n = cap > op + 512u ? (n < cap - op - 512u ? n : cap - op - 512u) : 0u;
+                    more_room = true;
+                    more_input = false;
+                }
+                stored_copy(p, (uint32_t)n);
+                stored_left -= (uint32_t)n;
+                if (stored_left != 0u) {
+                    susp_pos = stream_bit_pos();
+                    if (more_room) return ST_OUT_FULL;
+                    if (more_input && !res_final) return suspend_input(susp_pos);
+                    return fail(ST_TRUNCATED, 0, 0);
+                }
+                move_window_check();  // Deflate.hs:47
+                phase = bfinal_cur ? PH_TRAILER : PH_BLOCK;
+            } else if (phase == PH_TOKENS) {
+                const int st = token_loop_res();
+                if (st) return st;
+                move_window_check();  // Deflate.hs:47
+                phase = bfinal_cur ? PH_TRAILER : PH_BLOCK;
+            } else if (phase == PH_TRAILER) {
+                const uint64_t tpos = stream_bit_pos();
+                // (asked for before zlib_trailer() flushes: a flush to an odd position must be the last one)
+                if (br.avail() < (int64_t)(((8u - (br.rp & 7u)) & 7u) + 32u)) {
+                    if (!res_final) return suspend_input(tpos);
+                    return fail(ST_TRUNCATED, 0, 0);
+                }
+                const int st = zlib_trailer();
+                if (st) return st;
+                phase = PH_DONE;
+                return ST_OK;
+            } else {
+                return status;
+            }
+        }
+    }
+
+    // raw bytes in[p .. p + n) straight from HBM to the ring; the bit reader restarts behind them
+    PZG_FN void stored_copy(uint64_t p, uint32_t n)
+    {
+        const uint32_t lane = lane_id();
+        uint32_t done = 0;
+        constexpr uint32_t PIECE = RING / 4u;
+        while (done < n) {
+            uint32_t piece = n - done < PIECE ? n - done : PIECE;
+            if (op + piece - flushed > RING) flush_to(op & ~(uint64_t)15u);
+#pragma nounroll
+            for (uint32_t k0 = 0; k0 < piece; k0 += PZG_WAVE) {
+                const uint32_t k = k0 + lane;
+                const uint8_t v = in[p + done + (k < piece ? k : piece - 1u)];
+                sel_store(k < piece, &L.ring[((uint32_t)op + k) & RMASK], v, lane);
+            }
+            op += piece;
+            done += piece;
+        }
+        maybe_flush();
+        in_byte0 = p + n;
+        br.start(in, in_len, in_byte0);
+    }
+
+    // One call of the resumable decoder on decoder state `rs` (+ its LDS image behind it in HBM).
+    PZG_FN void run_resume(ResumeState *rs, uint32_t *lds_image, const uint8_t *in_, uint64_t in_len_, uint8_t *out_, uint64_t cap_,
+                           uint32_t final_input, StreamResult *res, uint32_t *chunks_out)
+    {
+        const uint32_t lane = lane_id();
+        in = in_;
+        in_len = in_len_;
+        dict = nullptr;
+        dict_len = 0;
+        hist_extra = 0;
+        gz_expect = 0;
+        pend_m0 = pend_m1 = 0;
+        pend_pos = 0;
+        in_byte0 = 0;
+        res_final = final_input;
+        phase = rs->phase;
+        bfinal_cur = rs->bfinal;
+        stored_left = rs->stored_left;
+        deferred = rs->deferred;
+        qn = rs->qn;
+        ow = rs->ow;
+        chunks = rs->chunks;
+        op = rs->op;
+        flushed = op & ~(uint64_t)15u;  // flush_to() moves whole 16-byte groups: the last few bytes of a call wait in the ring for the next
+        adler_a = rs->adler_a;
+        adler_b = rs->adler_b;
+        lit_e15 = rs->lit_e15;
+        dist_e15 = rs->dist_e15;
+        lit_n = rs->lit_n;
+        dist_n = rs->dist_n;
+        use_sub = rs->use_sub;
+        lit_sub_used = rs->lit_sub_used;
+        status = rs->status;
+        detail0 = rs->detail0;
+        detail1 = rs->detail1;
+        const uint32_t bit_skip = rs->bit_skip;
+        in_total_bits = rs->in_total * 8u;
+        if (phase == PH_HEADER && op == 0u && adler_a == 0u) adler_a = 1;  // a fresh decoder (all zeros)
+        const uint64_t flushed0 = flushed;
+        out = out_ - flushed0;  // this call's room starts at produced-byte `flushed0`
+        cap = flushed0 + cap_;
+        PZG_LANES_BEGIN(j)
+            PZG_LV(QT, j) = rs->QT[j];
+        PZG_LANES_END
+        // the LDS image (tables and the ring) as the previous call left it
+        {
+            uint32_t *ldsw = (uint32_t *)(void *)&L;
+            constexpr uint32_t NW = (uint32_t)(sizeof(WaveLds<RING_BITS>) / 4u);
+            if (phase != PH_HEADER || op != 0u) {
+#pragma nounroll
+                for (uint32_t k0 = 0; k0 < NW; k0 += PZG_WAVE)
+                    if (k0 + lane < NW) ldsw[k0 + lane] = lds_image[k0 + lane];
+            } else if (lane == 0u || PZG_WAVE == 1u) {
+                L.fixed_ready = 0u;
+            }
+            wave_sync();
+        }
+#if PZG_DEVICE_PASS && PZG_DMA_PREFETCH
+        br.pf = L.pf;
+#endif
+        br.start(in, in_len, 0);
+        br.rp += bit_skip;  // (< 8: the partly consumed first byte)
+        susp_pos = 0;
+        int st = ST_OK;
+        if (phase != PH_DONE) st = resume_decode();
+        else st = status;
+        if (st != ST_NEED_INPUT && st != ST_OUT_FULL) {
+            if (st != ST_OK) status = st;
+            phase = PH_DONE;
+            susp_pos = stream_bit_pos();
+        }
+        complete_pending();
+        flush_to(phase == PH_DONE ? op : op & ~(uint64_t)15u);  // what has been produced goes to this call's output (and into the checksum)
+#if PZG_DEVICE_PASS && PZG_DMA_PREFETCH
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no fetch into this wave's LDS may outlive the call
+#endif
+        wave_sync();
+        uint64_t used = susp_pos >> 3;
+        if (used > in_len) used = in_len;
+        {   // save
+            const uint32_t *ldsw = (const uint32_t *)(const void *)&L;
+            constexpr uint32_t NW = (uint32_t)(sizeof(WaveLds<RING_BITS>) / 4u);
+#pragma nounroll
+            for (uint32_t k0 = 0; k0 < NW; k0 += PZG_WAVE)
+                if (k0 + lane < NW) lds_image[k0 + lane] = ldsw[k0 + lane];
+            PZG_LANES_BEGIN(j)
+                rs->QT[j] = PZG_LV(QT, j);
+            PZG_LANES_END
+            if (lane == 0u || PZG_WAVE == 1u) {
+                rs->phase = phase;
+                rs->bfinal = bfinal_cur;
+                rs->stored_left = stored_left;
+                rs->deferred = deferred;
+                rs->qn = qn;
+                rs->bit_skip = phase == PH_DONE ? 0u : (uint32_t)(susp_pos & 7u);
+                rs->ow = ow;
+                rs->chunks = chunks;
+                rs->op = op;
+                rs->adler_a = adler_a;
+                rs->adler_b = adler_b;
+                rs->lit_e15 = lit_e15;
+                rs->dist_e15 = dist_e15;
+                rs->lit_n = lit_n;
+                rs->dist_n = dist_n;
+                rs->use_sub = use_sub;
+                rs->lit_sub_used = lit_sub_used;
+                rs->status = status;
+                rs->detail0 = detail0;
+                rs->detail1 = detail1;
+                rs->in_total += used;
+            }
+        }
+        res->status = st == ST_NEED_INPUT || st == ST_OUT_FULL ? st : status;
+        res->detail0 = detail0;
+        res->detail1 = detail1;
+        res->adler = (adler_b << 16) | adler_a;
+        res->gz_crc = 0;
+        res->out_len = flushed - flushed0;  // bytes delivered by THIS call
+        res->in_used = used;
+        *chunks_out = chunks;
     }
 };
 

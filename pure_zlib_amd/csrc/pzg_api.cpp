@@ -609,6 +609,81 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
     return PZG_RC_OK;
 }
 
+// ---- preset dictionaries (extension): a plain synchronous path on lane 0 -- pack, upload, launch, download ----------
+int dict_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint8_t *dict_base, const uint64_t *dict_off, const uint64_t *dict_len,
+              uint32_t n)
+{
+    Lane &ln = sh.lanes[0];
+    std::lock_guard<std::mutex> lk(ln.mu);
+    HIP_TRY(ctx, hipSetDevice(sh.device));
+    int rc = lane_prepare(ctx, ln);
+    if (rc != PZG_RC_OK) return rc;
+    std::vector<uint64_t> meta(6 * (size_t)n);  // in_off | in_len | out_off | out_cap | dict_off | dict_len, packed layout
+    uint64_t *ioff = meta.data(), *ilen = ioff + n, *ooff = ilen + n, *ocap = ooff + n, *doff = ocap + n, *dlen = doff + n;
+    size_t ip = 0, op = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        ioff[i] = ip;
+        ilen[i] = b.in_len[i];
+        ip += pad16(b.in_len[i]);
+        doff[i] = ip;
+        dlen[i] = dict_len[i];
+        ip += pad16(dict_len[i]);
+        ooff[i] = op;
+        ocap[i] = b.out_cap[i];
+        op += pad16(b.out_cap[i]);
+    }
+    std::vector<uint8_t> hin(ip + 16);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ilen[i]) memcpy(hin.data() + ioff[i], b.in_base + b.in_off[i], ilen[i]);
+        if (dlen[i]) memcpy(hin.data() + doff[i], dict_base + dict_off[i], dlen[i]);
+    }
+    if ((rc = arena_reserve(ctx, ln.d_in[0], ip + 64)) != PZG_RC_OK) return rc;
+    if ((rc = arena_reserve(ctx, ln.d_out[0], op + 64)) != PZG_RC_OK) return rc;
+    if ((rc = arena_reserve(ctx, ln.d_meta[0], 80 * (size_t)n + 64)) != PZG_RC_OK) return rc;
+    uint8_t *dm = (uint8_t *)ln.d_meta[0].p;
+    hipStream_t st = ln.s_k;
+    HIP_TRY(ctx, hipMemcpyAsync(dm, meta.data(), 48 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ln.d_in[0].p, hin.data(), ip, hipMemcpyHostToDevice, st));
+    pzg::InflateArgs a{};
+    a.in_base = (const uint8_t *)ln.d_in[0].p;
+    a.dict_base = a.in_base;
+    a.out_base = (uint8_t *)ln.d_out[0].p;
+    a.in_off = (const uint64_t *)dm;
+    a.in_len = a.in_off + n;
+    a.out_off = a.in_len + n;
+    a.out_cap = a.out_off + n;
+    a.dict_off = a.out_cap + n;
+    a.dict_len = a.dict_off + n;
+    a.out_len = (uint64_t *)(dm + 48 * (size_t)n);
+    a.in_used = a.out_len + n;
+    a.status = (int32_t *)(a.in_used + n);
+    a.adler = (uint32_t *)(a.status + n);
+    a.detail = a.adler + n;
+    a.n = n;
+    a.counter = ln.d_counter;
+    HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, st));
+    std::vector<uint8_t> res(32 * (size_t)n), hout(op + 16);
+    HIP_TRY(ctx, hipMemcpyAsync(res.data(), dm + 48 * (size_t)n, 32 * (size_t)n, hipMemcpyDeviceToHost, st));
+    if (op) HIP_TRY(ctx, hipMemcpyAsync(hout.data(), ln.d_out[0].p, op, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint64_t *olen = (const uint64_t *)res.data(), *used = olen + n;
+    const int32_t *stt = (const int32_t *)(used + n);
+    const uint32_t *ad = (const uint32_t *)(stt + n), *det = ad + n;
+    for (uint32_t i = 0; i < n; ++i) {
+        b.out_len[i] = olen[i];
+        b.status[i] = stt[i];
+        if (b.in_used) b.in_used[i] = used[i];
+        if (b.adler) b.adler[i] = ad[i];
+        if (b.detail) {
+            b.detail[2 * (size_t)i] = det[2 * (size_t)i];
+            b.detail[2 * (size_t)i + 1] = det[2 * (size_t)i + 1];
+        }
+        const uint64_t nb = olen[i] < ocap[i] ? olen[i] : ocap[i];
+        if (nb) memcpy(b.out_base + b.out_off[i], hout.data() + ooff[i], nb);
+    }
+    return PZG_RC_OK;
+}
+
 // longest first (by capacity): the launch order inside a shard; stable, so equal streams keep the caller's order
 void lpt_order(const uint64_t *out_cap, std::vector<uint32_t> &idx)
 {
@@ -724,7 +799,18 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
                         int32_t *status, uint32_t *detail, uint64_t *in_used, uint32_t *adler, uint32_t n,
                         uint32_t flags)
 {
+    return pzg_decompress_many_dict(ctx, in_base, in_off, in_len, nullptr, nullptr, nullptr, out_base, out_off, out_cap, out_len, status,
+                                    detail, in_used, adler, n, flags);
+}
+
+int pzg_decompress_many_dict(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len,
+                             const uint8_t *dict_base, const uint64_t *dict_off, const uint64_t *dict_len, uint8_t *out_base,
+                             const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status, uint32_t *detail,
+                             uint64_t *in_used, uint32_t *adler, uint32_t n, uint32_t flags)
+{
     if (!ctx) return PZG_RC_BAD_ARG;
+    const bool with_dict = dict_base && dict_off && dict_len;
+    if (with_dict && (flags & PZG_GZIP)) return PZG_RC_BAD_ARG;  // (preset dictionaries are a zlib-container notion)
     if (n == 0) return PZG_RC_OK;
     if (!in_base || !in_off || !in_len || !out_off || !out_cap || !out_len || !status) return PZG_RC_BAD_ARG;
     if ((flags & PZG_ASYNC) && !(flags & PZG_DEVICE_PTRS)) return PZG_RC_BAD_ARG;
@@ -744,6 +830,11 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
             a.in_used = in_used;
             a.adler = adler;
             a.n = n;
+            if (with_dict) {
+                a.dict_base = dict_base;
+                a.dict_off = dict_off;
+                a.dict_len = dict_len;
+            }
             return launch_device(ctx, *ctx->shards[0], a, flags);
         }
         // host pointers: validate the extents (a wrapped offset + length would size an arena far too small)
@@ -755,6 +846,14 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
         }
         if (any_out && !out_base) return PZG_RC_BAD_ARG;
         HostBatch b{in_base, in_off, in_len, out_base, out_off, out_cap, out_len, status, detail, in_used, adler, flags};
+        if (with_dict) {
+            bool any = false;
+            for (uint32_t i = 0; i < n; ++i) {
+                if (dict_off[i] + dict_len[i] < dict_off[i] || (dict_len[i] >> 32)) return PZG_RC_BAD_ARG;
+                any |= dict_len[i] != 0;
+            }
+            if (any) return dict_path(ctx, *ctx->shards[0], b, dict_base, dict_off, dict_len, n);
+        }
         const size_t S = ctx->shards.size();
         if (S == 1) {
             std::vector<uint32_t> idx(n);
@@ -801,6 +900,199 @@ int pzg_decompress_many(pzg_ctx *ctx, const uint8_t *in_base, const uint64_t *in
             std::lock_guard<std::mutex> g(ctx->err_mu);
             ctx->last_error = "C++ exception inside pzg_decompress_many";
         }
+        return PZG_RC_HIP_ERROR;
+    }
+}
+
+// ---- resumable decoders (decompressIncremental) ---------------------------------------------------------------------
+}  // extern "C"
+
+struct pzg_decoder {
+    pzg_ctx *ctx = nullptr;
+    uint32_t n = 0;
+    size_t stride = 0;
+    uint8_t *d_state = nullptr;  // n x stride: ResumeState + LDS image per decoder
+    uint32_t *d_counter = nullptr;
+    Arena d_in, d_out, d_meta;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+};
+
+extern "C" {
+
+int pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out)
+{
+    if (!ctx || !out || n == 0 || ctx->shards.size() != 1) return PZG_RC_BAD_ARG;
+    *out = nullptr;
+    try {
+        Shard &sh = *ctx->shards[0];
+        HIP_TRY(ctx, hipSetDevice(sh.device));
+        std::unique_ptr<pzg_decoder> d(new pzg_decoder());
+        d->ctx = ctx;
+        d->n = n;
+        d->stride = pzg::resume_state_bytes();
+        if (hipMalloc((void **)&d->d_state, d->stride * (size_t)n) != hipSuccess) return PZG_RC_NO_MEMORY;
+        if (hipMalloc((void **)&d->d_counter, 256) != hipSuccess) {
+            (void)hipFree(d->d_state);
+            return PZG_RC_NO_MEMORY;
+        }
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipMemsetAsync(d->d_state, 0, d->stride * (size_t)n, d->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(d->stream));
+        *out = d.release();
+        return PZG_RC_OK;
+    } catch (...) {
+        return PZG_RC_NO_MEMORY;
+    }
+}
+
+void pzg_decoder_destroy(pzg_decoder *dec)
+{
+    if (!dec) return;
+    (void)hipSetDevice(dec->ctx->shards[0]->device);
+    if (dec->stream) (void)hipStreamSynchronize(dec->stream);
+    for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta})
+        if (a->p) (void)hipFree(a->p);
+    if (dec->d_state) (void)hipFree(dec->d_state);
+    if (dec->d_counter) (void)hipFree(dec->d_counter);
+    if (dec->stream) (void)hipStreamDestroy(dec->stream);
+    delete dec;
+}
+
+int pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m)
+{
+    if (!dec) return PZG_RC_BAD_ARG;
+    pzg_ctx *ctx = dec->ctx;
+    std::lock_guard<std::mutex> g(dec->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->shards[0]->device));
+    if (!idx) {
+        HIP_TRY(ctx, hipMemsetAsync(dec->d_state, 0, dec->stride * (size_t)dec->n, dec->stream));
+    } else {
+        for (uint32_t j = 0; j < m; ++j) {
+            if (idx[j] >= dec->n) return PZG_RC_BAD_ARG;
+            HIP_TRY(ctx, hipMemsetAsync(dec->d_state + dec->stride * (size_t)idx[j], 0, pzg::resume_scalar_bytes(), dec->stream));
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(dec->stream));
+    return PZG_RC_OK;
+}
+
+int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len,
+                     const uint8_t *final_in, uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
+                     int32_t *state, uint32_t *detail, uint64_t *in_used, uint32_t *chunks, uint32_t *adler)
+{
+    if (!dec || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !state || !in_used || !chunks)
+        return PZG_RC_BAD_ARG;
+    pzg_ctx *ctx = dec->ctx;
+    if (!idx) m = dec->n;
+    if (m == 0) return PZG_RC_OK;
+    try {
+        for (uint32_t j = 0; j < m; ++j) {
+            if (idx && idx[j] >= dec->n) return PZG_RC_BAD_ARG;
+            if (out_cap[j] < 4096u || (out_cap[j] >> 40) || (in_len[j] >> 40)) return PZG_RC_BAD_ARG;
+            if (in_off[j] + in_len[j] < in_off[j] || out_off[j] + out_cap[j] < out_off[j]) return PZG_RC_BAD_ARG;
+        }
+        if (idx) {  // a decoder may appear once per call (each is continued by one wave)
+            std::vector<uint32_t> seen(idx, idx + m);
+            std::sort(seen.begin(), seen.end());
+            if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return PZG_RC_BAD_ARG;
+        }
+        std::lock_guard<std::mutex> g(dec->mu);
+        Shard &sh = *ctx->shards[0];
+        HIP_TRY(ctx, hipSetDevice(sh.device));
+        // packed staging: inputs, output room, meta (in_off | in_len | out_off | out_cap | out_len | in_used : u64[m];
+        // state | adler | chunks : 32-bit [m]; detail u32[2m]; final u8[m])
+        std::vector<uint64_t> meta(4 * (size_t)m);
+        uint64_t *ioff = meta.data(), *ilen = ioff + m, *ooff = ilen + m, *ocap = ooff + m;
+        size_t ip = 0, op = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            ioff[j] = ip;
+            ilen[j] = in_len[j];
+            ip += pad16(in_len[j]) + 16;
+            ooff[j] = op;
+            ocap[j] = out_cap[j];
+            op += pad16(out_cap[j]);
+        }
+        std::vector<uint8_t> hin(ip + 16);
+        for (uint32_t j = 0; j < m; ++j)
+            if (ilen[j]) memcpy(hin.data() + ioff[j], in_base + in_off[j], ilen[j]);
+        int rc;
+        const size_t meta_bytes = 72 * (size_t)m + 64;
+        if ((rc = arena_reserve(ctx, dec->d_in, ip + 64)) != PZG_RC_OK) return rc;
+        if ((rc = arena_reserve(ctx, dec->d_out, op + 64)) != PZG_RC_OK) return rc;
+        if ((rc = arena_reserve(ctx, dec->d_meta, meta_bytes)) != PZG_RC_OK) return rc;
+        uint8_t *dm = (uint8_t *)dec->d_meta.p;
+        hipStream_t st = dec->stream;
+        HIP_TRY(ctx, hipMemcpyAsync(dm, meta.data(), 32 * (size_t)m, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dec->d_in.p, hin.data(), ip, hipMemcpyHostToDevice, st));
+        std::vector<uint8_t> fin(m, 0);
+        if (final_in) memcpy(fin.data(), final_in, m);
+        uint8_t *d_final = dm + 68 * (size_t)m;
+        HIP_TRY(ctx, hipMemcpyAsync(d_final, fin.data(), m, hipMemcpyHostToDevice, st));
+        pzg::ResumeArgs a{};
+        a.state_stride = dec->stride;
+        a.in_base = (const uint8_t *)dec->d_in.p;
+        a.out_base = (uint8_t *)dec->d_out.p;
+        a.in_off = (const uint64_t *)dm;
+        a.in_len = a.in_off + m;
+        a.out_off = a.in_len + m;
+        a.out_cap = a.out_off + m;
+        a.out_len = (uint64_t *)(dm + 32 * (size_t)m);
+        a.in_used = a.out_len + m;
+        a.status = (int32_t *)(a.in_used + m);
+        a.adler = (uint32_t *)(a.status + m);
+        a.chunks = a.adler + m;
+        a.detail = a.chunks + m;
+        a.final_in = d_final;
+        a.counter = dec->d_counter;
+        // the decoders of this call: one launch when they are all of them (or one contiguous run), else one launch per run
+        uint32_t j0 = 0;
+        while (j0 < m) {
+            uint32_t j1 = j0 + 1;
+            const uint32_t first = idx ? idx[j0] : 0u;
+            if (!idx) j1 = m;
+            else
+                while (j1 < m && idx[j1] == first + (j1 - j0)) ++j1;
+            pzg::ResumeArgs r = a;
+            r.state_base = dec->d_state + dec->stride * (size_t)first;
+            r.in_off += j0;
+            r.in_len += j0;
+            r.out_off += j0;
+            r.out_cap += j0;
+            r.out_len += j0;
+            r.in_used += j0;
+            r.status += j0;
+            r.adler += j0;
+            r.chunks += j0;
+            r.detail += 2 * (size_t)j0;
+            r.final_in += j0;
+            r.n = j1 - j0;
+            HIP_TRY(ctx, pzg::launch_resume(r, sh.num_cus, st));
+            j0 = j1;
+        }
+        std::vector<uint8_t> res(36 * (size_t)m), hout(op + 16);
+        HIP_TRY(ctx, hipMemcpyAsync(res.data(), dm + 32 * (size_t)m, 36 * (size_t)m, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(hout.data(), dec->d_out.p, op, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const uint64_t *olen = (const uint64_t *)res.data(), *used = olen + m;
+        const int32_t *stt = (const int32_t *)(used + m);
+        const uint32_t *ad = (const uint32_t *)(stt + m), *ch = ad + m, *det = ch + m;
+        for (uint32_t j = 0; j < m; ++j) {
+            out_len[j] = olen[j];
+            state[j] = stt[j];
+            in_used[j] = used[j];
+            chunks[j] = ch[j];
+            if (adler) adler[j] = ad[j];
+            if (detail) {
+                detail[2 * (size_t)j] = det[2 * (size_t)j];
+                detail[2 * (size_t)j + 1] = det[2 * (size_t)j + 1];
+            }
+            if (olen[j]) memcpy(out_base + out_off[j], hout.data() + ooff[j], olen[j]);
+        }
+        return PZG_RC_OK;
+    } catch (const std::bad_alloc &) {
+        return PZG_RC_NO_MEMORY;
+    } catch (...) {
         return PZG_RC_HIP_ERROR;
     }
 }

@@ -194,6 +194,7 @@ extern "C" int pzg_error_message(const uint8_t *in, uint64_t in_len, int32_t sta
         else snprintf(buf, buf_len, "Header error: gzip: header crc mismatch");
         break;
     case PZG_E_GZIP_ISIZE: snprintf(buf, buf_len, "Checksum error: gzip: length mismatch: %u != %u", d0, d1); break;
+    case PZG_E_DICT: snprintf(buf, buf_len, "Header error: preset dictionary mismatch: %x != %x", d0, d1); break;  // extension
     default: snprintf(buf, buf_len, "unknown status %d", status); break;
     }
     return (int)strlen(buf);

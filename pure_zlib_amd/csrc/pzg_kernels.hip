@@ -73,7 +73,14 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(
             // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
             if (FIXUP && a->status[i] != ST_RETRY_FULL_RING) continue;
             Decoder<RING_BITS, GZIP> dec(lds);
-            dec.run(a->in_base + a->in_off[i], a->in_len[i], a->out_base + a->out_off[i], a->out_cap[i], &r);
+            const uint8_t *dict = nullptr;
+            uint32_t dict_len = 0;
+            if (!GZIP && a->dict_len) {  // extension (PZG_FDICT): this stream's preset dictionary, if it has one
+                const uint64_t dl = a->dict_len[i];
+                dict = a->dict_base + a->dict_off[i];
+                dict_len = dl > 0xffffffffull ? 0xffffffffu : (uint32_t)dl;
+            }
+            dec.run(a->in_base + a->in_off[i], a->in_len[i], a->out_base + a->out_off[i], a->out_cap[i], &r, dict, dict_len);
 #if defined(PZG_PROFILE)
             // diagnostic build: the 16 phase counters of stream i go to prof_out[16*i ..]
             if (threadIdx.x == 0 && a->prof_out)
@@ -85,20 +92,67 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(
             a->status[i] = r.status;
             if (!FIXUP && r.status == ST_RETRY_FULL_RING) atomicAdd(a->counter + 1, 1u);
             a->out_len[i] = r.out_len;
-            const bool gz_ok = GZIP && r.status == ST_OK;  // then the detail words carry the trailer's CRC-32 and ISIZE
             if (a->detail) {
-                a->detail[2 * (size_t)i] = gz_ok ? 0u : r.detail0;
-                a->detail[2 * (size_t)i + 1] = gz_ok ? 0u : r.detail1;
+                a->detail[2 * (size_t)i] = r.detail0;
+                a->detail[2 * (size_t)i + 1] = r.detail1;
             }
             if (a->in_used) a->in_used[i] = r.in_used;
             if (a->adler) a->adler[i] = GZIP ? 0u : r.adler;  // gzip: crc32_verify_kernel fills in the CRC-32
             if (GZIP) {
-                a->gz_expect[2 * (size_t)i] = r.detail0;
-                a->gz_expect[2 * (size_t)i + 1] = r.detail1;
+                a->gz_expect[2 * (size_t)i] = r.gz_crc;
+                a->gz_expect[2 * (size_t)i + 1] = (uint32_t)r.out_len;
             }
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The resumable decoder (decompressIncremental, Monad.hs:163-197): one launch continues a batch of suspended decoders,
+// one wave each, as far as their new input and output room go.  The RING_BITS = 15 instance: the whole window is the
+// LDS ring, so a decoder's history is part of the LDS image it keeps in HBM between calls.
+__global__ __launch_bounds__(64, 1) void inflate_resume_kernel(ResumeArgs a)
+{
+    __shared__ WaveLds<15> lds;
+    for (;;) {
+        uint32_t i = 0;
+        if (threadIdx.x == 0) i = atomicAdd(a.counter, 1u);
+        i = uni(i);
+        if (i >= a.n) break;
+        ResumeState *rs = (ResumeState *)(a.state_base + (size_t)i * a.state_stride);
+        uint32_t *image = (uint32_t *)(a.state_base + (size_t)i * a.state_stride + sizeof(ResumeState));
+        Decoder<15, false, true> dec(lds);
+        StreamResult r;
+        uint32_t chunks = 0;
+        dec.run_resume(rs, image, a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i], a.out_cap[i],
+                       a.final_in ? (uint32_t)a.final_in[i] : 0u, &r, &chunks);
+        if (threadIdx.x == 0) {
+            a.status[i] = r.status;
+            a.out_len[i] = r.out_len;
+            a.in_used[i] = r.in_used;
+            a.chunks[i] = chunks;
+            if (a.adler) a.adler[i] = r.adler;
+            if (a.detail) {
+                a.detail[2 * (size_t)i] = r.detail0;
+                a.detail[2 * (size_t)i + 1] = r.detail1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t resume_scalar_bytes() { return sizeof(ResumeState); }
+size_t resume_state_bytes() { return (sizeof(ResumeState) + sizeof(WaveLds<15>) + 255u) & ~(size_t)255u; }
+
+hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    uint32_t waves = (uint32_t)num_cus * 4u;  // 35.8 KiB of LDS per wave: four per CU
+    if (waves > a.n) waves = a.n;
+    hipLaunchKernelGGL(inflate_resume_kernel, dim3(waves), dim3(64), 0, stream, a);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -138,7 +192,9 @@ __global__ __launch_bounds__(64) void crc32_verify_kernel(InflateArgs a)
     }
     __syncthreads();
     for (uint32_t i = blockIdx.x; i < a.n; i += gridDim.x) {
-        if (a.status[i] != ST_OK) continue;  // (also: output larger than its capacity -- nothing stored to check)
+        // every member's ISIZE was checked as it was decoded; a mismatch is reported unless the CRC-32 is wrong as well
+        // (zlib's order).  (Output larger than its capacity: PZG_E_OUT_TOO_SMALL, nothing stored to check.)
+        if (a.status[i] != ST_OK && a.status[i] != ST_GZIP_ISIZE) continue;
         const uint64_t len = a.out_len[i];
         const uint8_t *p = a.out_base + a.out_off[i];
         const uint64_t slice = ((len + 63u) / 64u + 3u) & ~(uint64_t)3u;  // bytes per lane, a multiple of 4
@@ -183,19 +239,13 @@ __global__ __launch_bounds__(64) void crc32_verify_kernel(InflateArgs a)
             pw = gf2_mulmod(pw, pw);
         }
         if (lane == 63u) {
-            const uint32_t ours = len ? ~reg : 0u, theirs = a.gz_expect[2 * (size_t)i], isize = a.gz_expect[2 * (size_t)i + 1];
+            const uint32_t ours = len ? ~reg : 0u, theirs = a.gz_expect[2 * (size_t)i];
             if (a.adler) a.adler[i] = ours;
             if (theirs != ours) {
                 a.status[i] = ST_CHECKSUM;
                 if (a.detail) {
                     a.detail[2 * (size_t)i] = theirs;
                     a.detail[2 * (size_t)i + 1] = ours;
-                }
-            } else if (isize != (uint32_t)len) {
-                a.status[i] = ST_GZIP_ISIZE;
-                if (a.detail) {
-                    a.detail[2 * (size_t)i] = isize;
-                    a.detail[2 * (size_t)i + 1] = (uint32_t)len;
                 }
             }
         }

@@ -22,8 +22,36 @@ struct InflateArgs {
     uint64_t *prof_out;       // diagnostic builds only (-DPZG_PROFILE): 12 counters per stream, else null
     uint32_t n;
     uint32_t gzip;            // 0: zlib streams (RFC 1950, the reference's format); 1: gzip members (RFC 1952, an extension)
-    uint32_t *gz_expect;      // gzip only: 2n words of device scratch, the trailer's (CRC-32, ISIZE) of each stream
+    uint32_t *gz_expect;      // gzip only: 2n words of device scratch: the CRC-32 the output must have (from the member trailers)
+    // extension (PZG_FDICT): preset dictionaries, dict_base + dict_off[i] .. + dict_len[i] (0: none for stream i); null: none at all
+    const uint8_t *dict_base;
+    const uint64_t *dict_off;
+    const uint64_t *dict_len;
 };
+
+// one batched call of the resumable decoder (decompressIncremental): decoder i continues from its ResumeState
+struct ResumeArgs {
+    uint8_t *state_base;      // n slots of state_stride bytes: ResumeState + the LDS image (zeroed = a fresh decoder)
+    uint64_t state_stride;
+    const uint8_t *in_base;
+    const uint64_t *in_off;   // n: the unconsumed tail of the last call followed by the new input
+    const uint64_t *in_len;   // n
+    const uint8_t *final_in;  // n or null: nonzero = no more input will follow (running out is an error then)
+    uint8_t *out_base;
+    const uint64_t *out_off;  // n: this call's output room
+    const uint64_t *out_cap;  // n (>= 4096)
+    uint64_t *out_len;        // n: bytes delivered by this call
+    int32_t *status;          // n: PZG_DEC_NEED_INPUT / PZG_DEC_OUT_FULL / PZG_OK (done) / PZG_E_*
+    uint32_t *detail;         // 2n or null
+    uint64_t *in_used;        // n: input bytes the decoder is done with
+    uint32_t *adler;          // n or null
+    uint32_t *chunks;         // n: 32 KiB chunks the reference would have published so far (cumulative)
+    uint32_t *counter;
+    uint32_t n;
+};
+hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream);
+size_t resume_state_bytes();   // one decoder's slot: ResumeState + LDS image
+size_t resume_scalar_bytes();  // ... its ResumeState part (zeroing it makes the decoder fresh)
 
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);
 

@@ -115,6 +115,7 @@ _STATUS_CONSTRUCTOR = {
     _ffi.E_DATA_REMAINING: "DecompressionError",
     _ffi.E_GZIP_HEADER: "HeaderError",   # extension (PZG_GZIP): the reference has no gzip
     _ffi.E_GZIP_ISIZE: "ChecksumError",
+    _ffi.E_DICT: "HeaderError",         # extension (preset dictionaries)
 }
 
 
@@ -187,7 +188,8 @@ class Context:
         return float(self._L.pzg_last_kernel_ms(self._h))
 
     # -- raw batched call on host memory ----------------------------------------------------------
-    def decompress_many_raw(self, in_buf: np.ndarray, in_off, in_len, out_buf: np.ndarray, out_off, out_cap, gzip: bool = False):
+    def decompress_many_raw(self, in_buf: np.ndarray, in_off, in_len, out_buf: np.ndarray, out_off, out_cap, gzip: bool = False,
+                            dict_buf: Optional[np.ndarray] = None, dict_off=None, dict_len=None):
         """Thin wrapper of pzg_decompress_many on host numpy buffers.
         Returns (out_len u64[n], status i32[n], detail u32[n,2], in_used u64[n], adler u32[n])."""
         in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
@@ -201,6 +203,15 @@ class Context:
         in_used = np.zeros(n, dtype=np.uint64)
         adler = np.zeros(n, dtype=np.uint32)
         if n == 0:
+            return out_len, status, detail, in_used, adler
+        if dict_buf is not None:  # extension: one preset dictionary extent per stream (length 0 = none)
+            dict_off = np.ascontiguousarray(dict_off, dtype=np.uint64)
+            dict_len = np.ascontiguousarray(dict_len, dtype=np.uint64)
+            rc = self._L.pzg_decompress_many_dict(
+                self._h, in_buf.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, dict_buf.ctypes.data, dict_off.ctypes.data,
+                dict_len.ctypes.data, out_buf.ctypes.data, out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
+                status.ctypes.data, detail.ctypes.data, in_used.ctypes.data, adler.ctypes.data, n, 0)
+            _ffi.check(rc, self._h)
             return out_len, status, detail, in_used, adler
         rc = self._L.pzg_decompress_many(
             self._h, in_buf.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_buf.ctypes.data,
@@ -262,12 +273,16 @@ def _align(x, a=256):
 
 
 def decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = None,
-                    size_hint: Optional[Sequence[int]] = None, gzip: bool = False) -> List[Either]:
+                    size_hint: Optional[Sequence[int]] = None, gzip: bool = False,
+                    zdict: Optional[Sequence[Optional[bytes]]] = None) -> List[Either]:
     """decompressMany: every stream decoded by its own wavefront in one launch.
 
     zlib streams do not carry their decoded size, so each stream gets a capacity (size_hint[i] or a
     guess); streams that report PZG_E_OUT_TOO_SMALL are relaunched once with the exact size the
-    kernel measured."""
+    kernel measured.
+
+    zdict (EXTENSION, the reference skips DICTID: Zlib.hs:68): one preset dictionary per stream (None = none); a stream
+    whose header has FDICT set then decodes with it as history, as zlib.decompressobj(zdict=...) does."""
     ctx = ctx or default_context()
     chunked = [_to_chunks(s) for s in streams]
     flat = [b"".join(c) for c in chunked]
@@ -294,7 +309,15 @@ def decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = 
         for k, i in enumerate(todo):
             in_buf[int(in_off[k]):int(in_off[k]) + len(flat[i])] = np.frombuffer(flat[i], dtype=np.uint8)
         out_buf = np.zeros(opos + 16, dtype=np.uint8)
-        out_len, status, detail, in_used, _adler = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap, gzip)
+        dict_args = {}
+        if zdict is not None:
+            dl = np.array([len(zdict[i] or b"") for i in todo], dtype=np.uint64)
+            do = np.zeros(m, dtype=np.uint64)
+            do[1:] = np.cumsum(dl[:-1])
+            db = np.frombuffer(b"".join((zdict[i] or b"") for i in todo) + b"\0" * 16, dtype=np.uint8)
+            dict_args = dict(dict_buf=db, dict_off=do, dict_len=dl)
+        out_len, status, detail, in_used, _adler = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap, gzip,
+                                                                           **dict_args)
         retry = []
         for k, i in enumerate(todo):
             st = int(status[k])

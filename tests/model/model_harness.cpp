@@ -44,18 +44,17 @@ static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t c
     r->adler = sr.adler;
     r->out_len = sr.out_len;
     r->in_used = sr.in_used;
-    if (gzip && sr.status == pzg::ST_OK) {  // the verify pass of the gzip launch
-        const uint32_t ours = crc32_bits(out, sr.out_len);
+    if (gzip && (sr.status == pzg::ST_OK || sr.status == pzg::ST_GZIP_ISIZE)) {  // the verify pass of the gzip launch
+        const uint32_t ours = crc32_bits(out, sr.out_len < cap ? sr.out_len : cap);
         r->adler = ours;
-        r->detail0 = r->detail1 = 0;  // on success they carried the trailer's CRC-32 and ISIZE
-        if (sr.detail0 != ours) {
+        if (sr.out_len > cap) {
+            // (not stored: nothing to check; a length mismatch stays what it is)
+        } else if (sr.gz_crc != ours) {
             r->status = pzg::ST_CHECKSUM;
-            r->detail0 = sr.detail0;
+            r->detail0 = sr.gz_crc;
             r->detail1 = ours;
-        } else if (sr.detail1 != (uint32_t)sr.out_len) {
-            r->status = pzg::ST_GZIP_ISIZE;
-            r->detail0 = sr.detail1;
-            r->detail1 = (uint32_t)sr.out_len;
+        } else if (sr.status == pzg::ST_OK) {
+            r->detail0 = r->detail1 = 0;
         }
     }
     free(buf);
@@ -84,6 +83,55 @@ int pzm_decompress_gzip(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64
     else if (ring_bits == 11) run_one<11, true>(in, in_len, out, cap, r);
     else return -1;
     if (r->status == pzg::ST_RETRY_FULL_RING) run_one<15, true>(in, in_len, out, cap, r);
+    return 0;
+}
+
+// the resumable instance (decompressIncremental): one call on a decoder whose state (ResumeState + LDS image) the
+// caller keeps in `state` (pzm_resume_state_bytes() bytes, zeroed for a fresh decoder)
+uint32_t pzm_resume_state_bytes(void) { return (uint32_t)(sizeof(pzg::ResumeState) + sizeof(pzg::WaveLds<15>)); }
+
+int pzm_resume_feed(uint8_t *state, const uint8_t *in, uint64_t in_len, uint32_t final_input, uint8_t *out, uint64_t cap, pzm_result *r,
+                    uint32_t *chunks)
+{
+    auto *lds = (pzg::WaveLds<15> *)aligned_alloc(16, sizeof(pzg::WaveLds<15>));
+    memset(lds, 0xA5, sizeof(*lds));
+    uint8_t *buf = (uint8_t *)malloc(in_len + 16);
+    memset(buf, 0xEE, in_len + 16);
+    if (in_len) memcpy(buf + 8, in, in_len);
+    pzg::Decoder<15, false, true> dec(*lds);
+    pzg::StreamResult sr;
+    dec.run_resume((pzg::ResumeState *)state, (uint32_t *)(state + sizeof(pzg::ResumeState)), buf + 8, in_len, out, cap, final_input, &sr,
+                   chunks);
+    r->status = sr.status;
+    r->detail0 = sr.detail0;
+    r->detail1 = sr.detail1;
+    r->adler = sr.adler;
+    r->out_len = sr.out_len;
+    r->in_used = sr.in_used;
+    free(buf);
+    free(lds);
+    return 0;
+}
+
+// with a preset dictionary (PZG_FDICT extension): the 32 KiB-ring instance
+int pzm_decompress_dict(const uint8_t *in, uint64_t in_len, const uint8_t *dict, uint32_t dict_len, uint8_t *out, uint64_t cap, pzm_result *r)
+{
+    auto *lds = (pzg::WaveLds<15> *)aligned_alloc(16, sizeof(pzg::WaveLds<15>));
+    memset(lds, 0xA5, sizeof(*lds));
+    uint8_t *buf = (uint8_t *)malloc(in_len + 16);
+    memset(buf, 0xEE, in_len + 16);
+    if (in_len) memcpy(buf + 8, in, in_len);
+    pzg::Decoder<15, false> dec(*lds);
+    pzg::StreamResult sr;
+    dec.run(buf + 8, in_len, out, cap, &sr, dict, dict_len);
+    r->status = sr.status;
+    r->detail0 = sr.detail0;
+    r->detail1 = sr.detail1;
+    r->adler = sr.adler;
+    r->out_len = sr.out_len;
+    r->in_used = sr.in_used;
+    free(buf);
+    free(lds);
     return 0;
 }
 

@@ -236,15 +236,13 @@ def test_incremental_protocol_and_cli(gpu_ctx, tmp_path, capsys):
     assert isinstance(st, NeedMore)
     st = st.feed(b"")
     assert isinstance(st, NeedMore)
-    pieces = [z[i:i + 7000] for i in range(0, len(z), 7000)]
-    for p in pieces[:-1]:
+    got, pieces = [], [z[i:i + 7000] for i in range(0, len(z), 7000)]
+    for p in pieces:
         st = st.feed(p)
-        assert isinstance(st, NeedMore)
-    st = st.feed(pieces[-1])
-    got = []
-    while isinstance(st, Chunk):
-        got.append(st.chunk)
-        st = st.next()
+        while isinstance(st, Chunk):  # chunks come out as soon as 64 KiB are buffered, not at the end
+            got.append(st.chunk)
+            st = st.next()
+        assert isinstance(st, NeedMore) or p is pieces[-1]
     assert isinstance(st, Done) and b"".join(got) == d
     assert [len(c) for c in got[:-1]] == [32768] * (len(got) - 1) and 32768 <= len(got[-1]) < 65536
     bad = decompress_incremental(gpu_ctx).feed(b"\x78\x9d\x00")

@@ -148,3 +148,125 @@ def test_model_gzip_members(model, oracle, rb):
                 assert oo == om and ro.adler == rm.adler
             elif ro.status in (10, 18, 19):
                 assert (ro.detail0, ro.detail1) == (rm.detail0, rm.detail1) or ro.status == 18
+
+
+# ---- the resumable instance (decompressIncremental) and the two format extensions, still on the CPU ---------------
+
+class ModelDecoder:
+    """Drives pzm_resume_feed the way the host mirror drives pzg_decoder_feed: the unconsumed tail goes in front of the next
+    piece, a call that ran out of room is repeated, 32 KiB chunks are published as the device-side count says."""
+
+    def __init__(self, M, room):
+        self.M, self.room = M, room
+        self.state = C.create_string_buffer(M.pzm_resume_state_bytes())
+        self.tail, self.pending, self.published, self.total = b"", bytearray(), 0, bytearray()
+        self.events = [("NeedMore",)]
+
+    def feed(self, piece):
+        if not piece:
+            self.events.append(("NeedMore",))
+            return True
+        data = self.tail + piece
+        while True:
+            out = C.create_string_buffer(self.room)
+            r, ch = R(), C.c_uint32(0)
+            self.M.pzm_resume_feed(self.state, data, len(data), 0, out, self.room, C.byref(r), C.byref(ch))
+            self.pending += out.raw[:r.out_len]
+            self.total += out.raw[:r.out_len]
+            while self.published < ch.value:
+                assert len(self.pending) >= 32768
+                self.events.append(("Chunk", 32768))
+                del self.pending[:32768]
+                self.published += 1
+            data = data[r.in_used:]
+            if r.status != 102:  # (102: out of room -- same input again)
+                break
+        self.tail = data
+        if r.status == 101:
+            self.events.append(("NeedMore",))
+            return True
+        if r.status == 0:
+            self.events += [("Chunk", len(self.pending)), ("Done",)]
+        else:
+            self.events.append(("DecompError", r.status))
+        return False
+
+
+@pytest.fixture(scope="session")
+def model_lib(model):
+    M = C.CDLL(os.path.join(ROOT, "tests", "model", "libpzgmodel.so"))
+    M.pzm_resume_state_bytes.restype = C.c_uint32
+    M.pzm_resume_feed.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(R), C.POINTER(C.c_uint32)]
+    M.pzm_decompress_dict.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(R)]
+    return M
+
+
+def test_model_incremental_event_trace(model_lib, oracle):
+    """The ZlibDecoder protocol (Monad.hs:163-197, OutputWindow.hs:45-54): NeedMore / Chunk(32768) / Chunk(rest) / Done /
+    DecompError in exactly the reference's order, for the nine fixtures and seeded streams, fed 7000 bytes, 1 byte, 100
+    bytes at a time, with empty pieces, corrupted streams and output rooms from 4 KiB up."""
+    cases = []
+    for name in REF_CASES:
+        z, _gold = read_case(name)
+        cases += [(z, 7000, 70000), (z[:3000], 1, 4096)]
+    for seed in range(120):
+        n = [0, 1, 100, 5000, 70000, 200000][seed % 6]
+        d = corpus.mixed_data(n, seed) if seed % 3 else corpus.zipf_text(n, seed)
+        z = corpus.compress_variant(d, seed) if seed % 2 else zlib.compress(d, 1 + seed % 9)
+        if seed % 11 == 0:
+            z = corpus.corrupt(z, seed)
+        step = [1, 7, 100, 7000, 50000][seed % 5] if len(z) < 2000 or seed % 5 else 7000
+        cases.append((z, step, [4096, 70000, 300000][seed % 3]))
+    for k, (z, step, room) in enumerate(cases):
+        pieces = [z[i:i + step] for i in range(0, len(z), step)]
+        if k % 13 == 0:
+            pieces.insert(len(pieces) // 2, b"")
+        eo, ro, oo = oracle.trace(pieces)
+        dec = ModelDecoder(model_lib, room)
+        for p in pieces:
+            if not dec.feed(p):
+                break
+        assert dec.events == eo, (k, len(z), step, room, ro.status)
+        if ro.status == 0:
+            assert bytes(dec.total) == oo
+
+
+def test_model_preset_dictionary(model_lib, oracle):
+    """PZG_FDICT extension: dictionary installed as history (ring 15 instance) against zlib and the oracle."""
+    for seed in range(40):
+        zd = corpus.zipf_text([5, 300, 20000, 32768, 40000][seed % 5], seed + 100)
+        d = (zd[-200:] if seed % 2 else b"") + corpus.zipf_text(1000 + 997 * seed, seed)
+        co = zlib.compressobj(6, zdict=zd)
+        z = co.compress(d) + co.flush()
+        out = C.create_string_buffer(len(d) + 64)
+        r = R()
+        model_lib.pzm_decompress_dict(z, len(z), zd, len(zd), out, len(d) + 64, C.byref(r))
+        ro, oo = oracle.decompress_dict(z, zd)
+        assert r.status == 0 and out.raw[:r.out_len] == d == oo and ro.status == 0 and r.adler == zlib.adler32(d), seed
+        do = zlib.decompressobj(zdict=zd)
+        assert do.decompress(z) == d
+        bad = zd[:-1] + bytes([zd[-1] ^ 1])
+        model_lib.pzm_decompress_dict(z, len(z), bad, len(bad), out, len(d) + 64, C.byref(r))
+        ro, _ = oracle.decompress_dict(z, bad)
+        assert r.status == ro.status == 20 and (r.detail0, r.detail1) == (ro.detail0, ro.detail1)
+
+
+def test_model_gzip_multi_member(model, oracle):
+    import gzip
+    for seed in range(30):
+        parts = [corpus.mixed_data((seed * 977 + 131 * k) % 40000, seed + k) for k in range(1 + seed % 4)]
+        g = b"".join(corpus.gzip_member(p, seed + k) if k % 2 else gzip.compress(p, 1 + seed % 9) for k, p in enumerate(parts))
+        d = b"".join(parts)
+        assert gzip.decompress(g) == d
+        for rb in (15, 11):
+            r, out = model(g, len(d) + 8, rb, gzip=True)
+            assert r.status == 0 and out == d and r.adler == zlib.crc32(d) and r.in_used == len(g), (seed, rb, r.status)
+        for c in range(6):
+            gc = corpus.corrupt(g, seed * 32 + c)
+            ro, oo = oracle.gzip_decompress(gc, len(d) + 8)
+            rm, om = model(gc, len(d) + 8, 15, gzip=True)
+            if rm.status == 14 and ro.status in (10, 19):
+                continue
+            assert ro.status == rm.status, (seed, c, ro.status, rm.status, ro.message)
+            if ro.status in (10, 19):
+                assert (ro.detail0, ro.detail1) == (rm.detail0, rm.detail1)
