@@ -39,17 +39,23 @@ def log(*a):
 
 
 def traffic_from_profiles(args, ring_bits, n):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs)
-    of this same command; recorded in profiles/traffic.json by hand after each profiling session."""
+    """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, counters only) of
+    this same command on the committed kernel; recorded in profiles/traffic.json after each profiling session
+    (tests/tools/profile_round.sh).  Returns (bytes or None, where the number comes from)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         for e in t["entries"]:
-            if e["workload"] == args.workload and e["ring_bits"] == ring_bits and e["streams"] == n:
-                return e["hbm_bytes_per_launch"]
+            if e["workload"] == args.workload and e["ring_bits"] == ring_bits and e["streams"] == n and bool(e.get("gzip")) == bool(args.gzip):
+                src = {"file": e.get("file", t.get("source")), "counters": "FETCH_SIZE + WRITE_SIZE (TCC_EA0_RDREQ / WRREQ based), one rocprofv3 --pmc pass each",
+                       "fetch_bytes": e["fetch_bytes"], "write_bytes": e["write_bytes"],
+                       "fetch_correction": e.get("fetch_correction", "raw (byte-granular far-window gathers dominate the reads; the x2 of the guide applies "
+                                                                     "to 16 B/lane streaming reads only)"),
+                       "kernel_revision": e.get("kernel_revision")}
+                return e["hbm_bytes_per_launch"], src
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def build_pool(args):
@@ -98,7 +104,8 @@ def main():
     ap.add_argument("--blob-bytes", type=int, default=32768)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--pool", type=int, default=2048, help="distinct blobs; the batch replicates them at distinct addresses")
-    ap.add_argument("--cpu-sample", type=int, default=24576, help="streams timed on the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="streams of the ONE-THREAD CPU baseline legs (rank 0, N=1); 0 = no CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline legs (0 = every core)")
     ap.add_argument("--adler-gib", type=float, default=16.0, help="Adler-32 microbench size (BASELINE config 2); 0 = skip")
     ap.add_argument("--ring-bits", type=int, default=0, help="LDS ring size class 11..15 (0 = library default); 15 = the whole 32 KiB window in LDS")
     ap.add_argument("--no-ab", action="store_true", help="skip the secondary measurement of the pure 32 KiB LDS-ring variant")
@@ -306,7 +313,8 @@ def main():
                 "read_only_GBps": round(comp_total / (k_ms * 1e-3) / 1e9, 2),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": round(k_ms, 4),
-                "traffic": traffic_from_profiles(args, ring_bits, n),
+                "traffic": traffic_from_profiles(args, ring_bits, n)[0],
+                "traffic_source": traffic_from_profiles(args, ring_bits, n)[1],
             },
         }
         if ab is not None:
@@ -330,39 +338,56 @@ def main():
         }
         del h_out
 
-    # ---- CPU baseline: the oracle ("port") on a bounded sample, rank 0 at N=1 only -----------------
+    # ---- CPU baseline, rank 0 at N=1 only: the oracle ("port": the bit-at-a-time restatement of pure-zlib) and system
+    # zlib, on this box's host cores.  All cores: the WHOLE timed batch.  One thread: a bounded sample of it (the whole
+    # batch would take most of a minute per decoder).  A reported baseline, not a target.
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import oracle as O
-        m = min(args.cpu_sample, n)
-        s_in_off = in_off[:m].astype(np.uint64)
-        s_in_end = (in_off[:m] + in_len[:m]).astype(np.uint64)
-        # oracle's batch helper takes (off[n+1]) extents: build per-stream pairs
         L = O.lib()
-        obuf = np.zeros(int(out_cap[:m].max()) + 64, dtype=np.uint8)
-        res = O.Result()
-        t0c = time.perf_counter()
-        nbytes = 0
-        for k in range(m):
-            L.pzo_decompress(h_in.ctypes.data + int(s_in_off[k]), int(s_in_end[k] - s_in_off[k]),
-                             obuf.ctypes.data, int(out_cap[k]), res)
-            nbytes += res.out_len
-            if res.status != 0:
-                raise SystemExit("oracle rejected a bench stream")
-        dtc = time.perf_counter() - t0c
-        t0z = time.perf_counter()
-        for k in range(m):
-            zlib.decompress(h_in[int(s_in_off[k]):int(s_in_end[k])].tobytes())
-        dtz = time.perf_counter() - t0z
+        cores = os.cpu_count() or 1
+        nthreads = max(1, min(cores, args.cpu_threads or cores))
+
+        import ctypes as C
+        for fn in (L.pzo_decompress_many_mt, L.pzo_zlib_many_mt):  # oracle/pz_baseline_mt.c: POSIX threads over the batch layout
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+            fn.restype = C.c_uint32
+        u_off, u_len, u_cap = (np.ascontiguousarray(a, dtype=np.uint64) for a in (in_off, in_len, out_cap))
+
+        def timed(fn, count, threads):
+            nb = C.c_uint64(0)
+            t0 = time.perf_counter()
+            bad = fn(h_in.ctypes.data, u_off.ctypes.data, u_len.ctypes.data, u_cap.ctypes.data, count, threads, C.byref(nb))
+            dt = time.perf_counter() - t0
+            if bad:
+                raise SystemExit(f"the CPU baseline rejected {bad} bench stream(s)")
+            return int(nb.value), dt
+
+        m1 = min(args.cpu_sample, n)
+        nb_o1, dt_o1 = timed(L.pzo_decompress_many_mt, m1, 1)
+        nb_z1, dt_z1 = timed(L.pzo_zlib_many_mt, m1, 1)
+        nb_oa, dt_oa = timed(L.pzo_decompress_many_mt, n, nthreads)
+        nb_za, dt_za = timed(L.pzo_zlib_many_mt, n, nthreads)
+        model = ""
+        try:
+            with open("/proc/cpuinfo") as f:
+                model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
+        except Exception:
+            pass
         result["cpu_baseline"] = {
-            "value": round(nbytes / dtc / 2**30, 4),
+            "value": round(nb_oa / dt_oa / 2**30, 3),
             "unit": "GiB/s",
-            "cores": 1,
+            "cores": nthreads,
             "kind": "port",
-            "sample": f"first {m} streams of the same batch ({nbytes / 2**20:.0f} MiB decoded) through oracle/pz_oracle.c "
-                      f"(bit-at-a-time restatement of pure-zlib), 1 thread, {dtc:.1f}s",
-            "host_cores_available": os.cpu_count(),
-            "system_zlib_1thread_GiBps": round(nbytes / dtz / 2**30, 3),
-            "note": "the Haskell reference itself cannot run here (no GHC); README.md:6-8 puts it ~100x below C zlib",
+            "sample": f"all {n} streams of the timed batch ({nb_oa / 2**20:.0f} MiB decoded) through oracle/pz_oracle.c on {nthreads} "
+                      f"threads, {dt_oa:.1f}s",
+            "one_thread_GiBps": round(nb_o1 / dt_o1 / 2**30, 4),
+            "one_thread_sample": f"first {m1} streams ({nb_o1 / 2**20:.0f} MiB), {dt_o1:.1f}s",
+            "system_zlib_all_cores_GiBps": round(nb_za / dt_za / 2**30, 2),
+            "system_zlib_one_thread_GiBps": round(nb_z1 / dt_z1 / 2**30, 3),
+            "host": model,
+            "host_cores_available": cores,
+            "note": "the Haskell reference itself cannot run here (no GHC); README.md:6-8 of the reference puts it ~100x below C zlib. "
+                    "system zlib = libz's uncompress() on the same batch and threads (oracle/pz_baseline_mt.c).",
         }
 
     # ---- BASELINE config 2: Adler-32 over one large buffer (HBM-bound microbench) -------------------
@@ -397,6 +422,28 @@ def main():
             "kernel_ms_median": round(med, 3),
             "matches_zlib_adler32": bool(got == exp),
         }
+        # ... and its batched form: 64 KiB buffers, one wave each, pzg_adler32_many
+        nbuf = nb // 65536
+        if nbuf >= 1024:
+            d_off = torch.arange(nbuf, dtype=torch.int64, device=dev) * 65536
+            d_len = torch.full((nbuf,), 65536, dtype=torch.int64, device=dev)
+            d_many = torch.zeros(nbuf, dtype=torch.int32, device=dev)
+            msb = []
+            for it in range(6):
+                ctx.adler32_many_device(buf.data_ptr(), d_off.data_ptr(), d_len.data_ptr(), d_many.data_ptr(), nbuf, sync=True)
+                if it:
+                    msb.append(ctx.last_kernel_ms())
+            gotb = d_many.cpu().numpy().view(np.uint32)
+            ks = np.random.default_rng(9).integers(0, nbuf, size=64)
+            okb = all(int(gotb[k]) == zlib.adler32(buf[int(k) * 65536:(int(k) + 1) * 65536].cpu().numpy().tobytes()) for k in ks)
+            medb = float(np.median(msb))
+            result["adler32_microbench"]["batched"] = {
+                "workload": f"{nbuf} x 64 KiB buffers, one wave each",
+                "GBps": round(nbuf * 65536 / (medb * 1e-3) / 1e9, 1),
+                "frac_of_8000": round(nbuf * 65536 / (medb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel_ms_median": round(medb, 3),
+                "matches_zlib_adler32": bool(okb),
+            }
         del buf
 
     if rank == 0:

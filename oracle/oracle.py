@@ -54,7 +54,8 @@ def build(force=False):
     so = os.path.join(_HERE, "libpzoracle.so")
     src = os.path.join(_HERE, "pz_oracle.c")
     hdr = os.path.join(_HERE, "pz_oracle.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    mt = os.path.join(_HERE, "pz_baseline_mt.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(mt)):
         subprocess.check_call(["make", "-C", _HERE, "libpzoracle.so"], stdout=subprocess.DEVNULL)
     return so
 

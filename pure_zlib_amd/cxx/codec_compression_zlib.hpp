@@ -246,10 +246,10 @@ inline Either decompress(const LazyByteString &ifile, Context &ctx = Context::sh
 // ---- ZlibDecoder (Monad.hs:163-167) and decompressIncremental (Zlib.hs:29-30) -------------------------
 //   data ZlibDecoder s = NeedMore (ByteString -> ST s (ZlibDecoder s)) | Chunk ByteString (ST s (ZlibDecoder s))
 //                      | Done | DecompError DecompressionError
-// A wavefront cannot be suspended mid-stream, so this decoder buffers what it is fed and re-decodes the
-// accumulated input on the GPU at each feed; it answers NeedMore while the stream is incomplete and
-// then hands the output out as 32,768-byte Chunks followed by the remainder, the sizes
-// moveWindow/finalize produce (Monad.hs:338-358, OutputWindow.hs:42-60).  No CPU inflate anywhere.
+// The suspended decoder lives on the device (pzg_decoder, include/pzg.h): feed() is one launch that continues it from
+// where it stopped -- nothing is re-decoded -- and reports how many 32,768-byte chunks the reference has published by
+// then (moveWindow after every match and block end once 64 KiB are buffered: Monad.hs:338-347, OutputWindow.hs:45-54),
+// so Chunks, NeedMore, Done and DecompError come out in exactly the reference's order.  No CPU inflate anywhere.
 class ZlibDecoder {
   public:
     enum State { NeedMore, Chunk, Done, DecompError };
@@ -260,16 +260,32 @@ class ZlibDecoder {
     {
         if (state_ != NeedMore) throw std::logic_error("feed: the decoder is not in NeedMore");
         if (chunk.empty()) return;  // S.uncons = Nothing: ask again (Monad.hs:185-197)
-        acc_ += chunk;
-        Either r = decompress(fromStrict(acc_), *ctx_);
-        if (!r.is_right) {
-            if (r.left.status == PZG_E_TRUNCATED) return;  // the stream is not complete yet
-            error_ = r.left;
-            state_ = DecompError;
-            return;
+        tail_ += chunk;
+        all_ += chunk;
+        for (;;) {
+            std::vector<uint8_t> out(kRoom);
+            const uint64_t in_off = 0, in_len = tail_.size(), out_off = 0, out_cap = kRoom;
+            uint64_t out_len = 0, in_used = 0;
+            int32_t st = 0;
+            uint32_t det[2] = {0, 0}, chunks = 0;
+            static const uint8_t none = 0;
+            const int rc = pzg_decoder_feed(dec_.get(), nullptr, 1, tail_.empty() ? &none : (const uint8_t *)tail_.data(), &in_off, &in_len,
+                                            nullptr, out.data(), &out_off, &out_cap, &out_len, &st, det, &in_used, &chunks, nullptr);
+            if (rc != PZG_RC_OK) throw std::runtime_error(std::string("pzg_decoder_feed: ") + pzg_last_error(ctx_->handle()));
+            pending_.append((const char *)out.data(), out_len);
+            tail_.erase(0, in_used);
+            device_chunks_ = chunks;
+            if (st == PZG_DEC_OUT_FULL) continue;  // out of room: the rest of the input, fresh room
+            if (st == PZG_DEC_NEED_INPUT) {
+                terminal_ = NeedMore;
+            } else if (st == PZG_OK) {
+                terminal_ = Done;
+            } else {
+                terminal_ = DecompError;
+                error_ = detail::error_from_status(all_, st, det);
+            }
+            break;
         }
-        out_ = std::move(r.right);
-        pos_ = 0;
         advance();
     }
     // Chunk c m: the chunk, then run the continuation m
@@ -281,31 +297,39 @@ class ZlibDecoder {
     }
     const DecompressionError &error() const { return error_; }
 
-    explicit ZlibDecoder(Context &ctx = Context::shared()) : ctx_(&ctx) {}
+    explicit ZlibDecoder(Context &ctx = Context::shared()) : ctx_(&ctx)
+    {
+        pzg_decoder *d = nullptr;
+        const int rc = pzg_decoder_create(ctx.handle(), 1, &d);
+        if (rc != PZG_RC_OK) throw std::runtime_error(std::string("pzg_decoder_create: ") + pzg_strerror(rc));
+        dec_ = std::shared_ptr<pzg_decoder>(d, pzg_decoder_destroy);
+    }
 
   private:
-    static constexpr size_t kExcess = 32768;  // OutputWindow.hs:42-43 excessChunkSize
+    static constexpr size_t kExcess = 32768;    // OutputWindow.hs:42-43 excessChunkSize
+    static constexpr size_t kRoom = 256 * 1024;  // output room per launch
+    // the next constructor: the chunks moveWindow has published so far, then what the last feed ended in
     void advance()
     {
-        if (final_published_) {
-            state_ = Done;
-            return;
-        }
-        const size_t left = out_.size() - pos_;
-        if (left >= 2 * kExcess) {  // emitExcess: a 32 KiB piece whenever >= 64 KiB are buffered
-            cur_ = out_.substr(pos_, kExcess);
-            pos_ += kExcess;
-        } else {  // finalizeWindow publishes whatever is left (possibly empty)
-            cur_ = out_.substr(pos_);
-            pos_ = out_.size();
+        if (published_ < device_chunks_) {
+            cur_ = pending_.substr(0, kExcess);
+            pending_.erase(0, kExcess);
+            ++published_;
+            state_ = Chunk;
+        } else if (terminal_ == Done && !final_published_) {  // finalize (Monad.hs:349-353): whatever is left, as one chunk
+            cur_ = pending_;
+            pending_.clear();
             final_published_ = true;
+            state_ = Chunk;
+        } else {
+            state_ = terminal_;
         }
-        state_ = Chunk;
     }
     Context *ctx_;
-    State state_ = NeedMore;
-    ByteString acc_, out_, cur_;
-    size_t pos_ = 0;
+    std::shared_ptr<pzg_decoder> dec_;
+    State state_ = NeedMore, terminal_ = NeedMore;
+    ByteString tail_, all_, pending_, cur_;
+    uint32_t published_ = 0, device_chunks_ = 0;
     bool final_published_ = false;
     DecompressionError error_;
 };

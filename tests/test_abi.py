@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     L = _ffi.lib()
-    assert L.pzg_version() == 1
+    assert L.pzg_version() == 2  # (major << 16) | minor: 0.2
     assert b"no CPU fallback" in L.pzg_strerror(_ffi.RC_NO_DEVICE)
 
 
