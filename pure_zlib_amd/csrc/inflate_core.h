@@ -935,16 +935,29 @@ struct Decoder {
         qn += 1u;
     }
 
+    // ---- table geometry --------------------------------------------------------------------------------------------
+    // Dynamic blocks: 2^8-entry primary tables + second-level tables (above).  Fixed-Huffman blocks (FX; not in the
+    // resumable instance) get tables of their own shape: the fixed literal/length code is at most 9 bits, so a 2^9-entry
+    // table over the two primary tables' LDS resolves every code in ONE lookup (its 9-bit literals 144..255 would
+    // otherwise all take the second-level path), and the 5-bit distance code takes a 2^5-entry table in the
+    // second-level pool.  Same LDS, no second lookups, no long codes.
+    static constexpr bool FX_TABLES = !RES;
+    template <bool FX> static constexpr uint32_t lit_bits() { return FX ? 9u : (uint32_t)LIT_BITS; }
+    template <bool FX> static constexpr uint32_t dist_bits() { return FX ? 5u : (uint32_t)DIST_BITS; }
+    template <bool FX> PZG_FN const uint32_t *lit_table() const { return L.lit_lut; }  // (FX: runs on into dist_lut, its neighbour)
+    template <bool FX> PZG_FN const uint32_t *dist_table() const { return FX ? L.sub : L.dist_lut; }
+
     // ---- Deflate.hs:106-120 runInflate: one token, every bit checked against the stream end ------
     // Used near the end of the stream and for whatever window_append() does not handle itself
     // (end-of-block, codes longer than the primary tables, every error).  A literal or match is put
     // on the token queue like the windows' tokens.
     // Returns ST_OK (token consumed), 1000 (end of block consumed) or an error status.
     static constexpr int STEP_EOB = 1000;
+    template <bool FX>
     PZG_FN int token_step_checked()
     {
         uint32_t bits = br.peek32();
-        uint32_t e = uni(L.lit_lut[bits & ((1u << LIT_BITS) - 1u)]);
+        uint32_t e = uni(lit_table<FX>()[bits & ((1u << lit_bits<FX>()) - 1u)]);
         uint32_t kind = ent_kind_lit(e);
         if (kind == K_SUB) {  // second level: one more (wave-uniform) lookup
             e = uni(L.sub[ent_val(e) + ((bits >> LIT_BITS) & ((1u << ent_n(e)) - 1u))]);
@@ -967,7 +980,7 @@ struct Decoder {
             const uint32_t len = ent_len_base(e) + ((bits >> n) & ((1u << (tot - n)) - 1u));
             br.drop(tot);
             bits = br.peek32();
-            uint32_t d = uni(L.dist_lut[bits & ((1u << DIST_BITS) - 1u)]);
+            uint32_t d = uni(dist_table<FX>()[bits & ((1u << dist_bits<FX>()) - 1u)]);
             uint32_t dk = ent_kind_dist(d);
             if (dk == K_SUB) {
                 d = uni(L.sub[ent_val(d) + ((bits >> DIST_BITS) & ((1u << ent_n(d)) - 1u))]);
@@ -1019,23 +1032,28 @@ struct Decoder {
     struct Spec {
         uint32_t w_lo, w_hi, e, w2, d;
     };
+    template <bool FX>
     PZG_FN void spec_bits(Spec &t, uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r)
     {
         t.w_lo = funnel(mid, lo, r);  // 64 stream bits from the token's first
         t.w_hi = funnel(hi, mid, r);
-        t.e = L.lit_lut[t.w_lo & ((1u << LIT_BITS) - 1u)];
+        t.e = lit_table<FX>()[t.w_lo & ((1u << lit_bits<FX>()) - 1u)];
     }
     PZG_FN void spec_sub(Spec &t)
     {
         const bool is_sub = (t.e & (ENT_STOP | (15u << 8))) == (ENT_STOP | ((uint32_t)K_SUB << 8));
-        const uint32_t i2 = is_sub ? ent_val(t.e) + ((t.w_lo >> LIT_BITS) & ((1u << ent_n(t.e)) - 1u)) : 0u;
+        uint32_t i2 = is_sub ? ent_val(t.e) + ((t.w_lo >> LIT_BITS) & ((1u << ent_n(t.e)) - 1u)) : 0u;
+#if PZG_DEVICE_PASS
+        asm("" : "+v"(i2));  // every lane looks up (entry 0 where there is nothing to): no EXEC narrowing, no branch around the load
+#endif
         const uint32_t e2 = L.sub[i2];
         t.e = is_sub ? e2 : t.e;
     }
+    template <bool FX>
     PZG_FN void spec_dist(Spec &t)
     {
         t.w2 = funnel(t.w_hi, t.w_lo, t.e);  // bits after the length code and its extra bits: the entry's [4:0], <= 20
-        t.d = L.dist_lut[t.w2 & ((1u << DIST_BITS) - 1u)];
+        t.d = dist_table<FX>()[t.w2 & ((1u << dist_bits<FX>()) - 1u)];
     }
     // tb = the token's length in bits, >= 128 if it is not a plain literal/match (the walk stops there); tk = the token.
     // The entry layout (see the top of this file) makes this 14 vector instructions: a literal's entry IS its token, a
@@ -1051,27 +1069,29 @@ struct Decoder {
         tb = (e + (d & m)) & 0xffu;                           // byte sums: either stop bit (0x80) pushes it to >= 128
         tk = (tk_match & m) | (e & ~m);
     }
+    template <bool FX>
     PZG_FN void decode_at(uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r, uint32_t &tb, uint32_t &tk)
     {
         Spec t;
-        spec_bits(t, lo, mid, hi, r);
-        if (use_sub) spec_sub(t);  // wave-uniform
-        spec_dist(t);
+        spec_bits<FX>(t, lo, mid, hi, r);
+        if (!FX && use_sub) spec_sub(t);  // wave-uniform
+        spec_dist<FX>(t);
         spec_finish(t, tb, tk);
     }
     // two independent decodes, stage by stage
+    template <bool FX>
     PZG_FN void decode_pair(uint32_t lo0, uint32_t mid0, uint32_t hi0, uint32_t mid1, uint32_t hi1, uint32_t r, uint32_t &tb0,
                             uint32_t &tk0, uint32_t &tb1, uint32_t &tk1)
     {
         Spec a, b;
-        spec_bits(a, lo0, mid0, hi0, r);
-        spec_bits(b, hi0, mid1, hi1, r);
-        if (use_sub) {  // wave-uniform
+        spec_bits<FX>(a, lo0, mid0, hi0, r);
+        spec_bits<FX>(b, hi0, mid1, hi1, r);
+        if (!FX && use_sub) {  // wave-uniform
             spec_sub(a);
             spec_sub(b);
         }
-        spec_dist(a);
-        spec_dist(b);
+        spec_dist<FX>(a);
+        spec_dist<FX>(b);
         spec_finish(a, tb0, tk0);
         spec_finish(b, tb1, tk1);
     }
@@ -1143,6 +1163,7 @@ struct Decoder {
     // Precondition: br.window_ok(): at least WINDOW_MIN_BITS real bits follow the cursor, so every token that
     // starts within the next 64 bits (at most 48 bits long) lies inside the stream; qn < QCAP.
     // Returns true when the token now at the cursor must go through token_step_checked().
+    template <bool FX>
     PZG_FN bool window_append()
     {
         // lane k needs the three dwords that hold stream bits [k, k+96) from the cursor
@@ -1156,7 +1177,7 @@ struct Decoder {
                 const uint32_t lo = sel == 0u ? B0 : sel == 1u ? B1 : B2;
                 const uint32_t mid = sel == 0u ? B1 : sel == 1u ? B2 : B3;
                 const uint32_t hi = sel == 0u ? B2 : sel == 1u ? B3 : B4;
-                decode_at(lo, mid, hi, r, PZG_LV(TB, k), PZG_LV(TK, k));
+                decode_at<FX>(lo, mid, hi, r, PZG_LV(TB, k), PZG_LV(TK, k));
             PZG_LANES_END
         }
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
@@ -1188,6 +1209,7 @@ struct Decoder {
     // independent, so their LDS round trips overlap, and the per-window bookkeeping is paid once.
     // Precondition: br.window2_ok(); qn < QCAP.  Falls back to the first half alone when the queue
     // cannot take both.  Returns true when the token now at the cursor must go through token_step_checked().
+    template <bool FX>
     PZG_FN bool window_append2()
     {
         LaneVec<uint32_t> TB0, TK0, TB1, TK1;
@@ -1213,14 +1235,14 @@ struct Decoder {
                 mid1 = d + 3u >= 64u ? n3 : mid1;
                 hi1 = d + 4u >= 64u ? n4 : hi1;
             }
-            decode_pair(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
+            decode_pair<FX>(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
         }
 #else
         {
             const uint32_t i0 = br.chunk0 + (br.rp >> 5), boff = br.rp & 31u;
             PZG_LANES_BEGIN(k)
                 const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
-                decode_pair(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
+                decode_pair<FX>(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
                             PZG_LV(TB0, k), PZG_LV(TK0, k), PZG_LV(TB1, k), PZG_LV(TK1, k));
             PZG_LANES_END
         }
@@ -1409,6 +1431,16 @@ struct Decoder {
 #endif
             PZG_T0(t_d);
             const uint32_t run = lane_get(INCL, v - 1u);
+            if (run == v) {
+                // one byte per token: nothing but literals (a match is three bytes or more).  Byte j IS token j's byte:
+                // no announcements, no gathers -- literal-heavy data (little or no redundancy) spends its time here.
+                PZG_LANES_BEGIN(j)
+                    sel_store(j < v, &L.ring[(op32 + j) & RMASK], (uint8_t)(PZG_LV(QT, j) >> 8), j);
+                PZG_LANES_END
+                op += run;
+                if (RES) ow += run;  // (no match: no moveWindow check)
+                PZG_ACC(11, t_d);
+            } else {
             // Which token does output byte o belong to?  Token t announces itself at lane START[t] of its pass (one
             // crossbar scatter); the tokens sit in the queue in output order, so byte o belongs to token
             // (number of announcements at offsets <= o) - 1.  Lanes that send nothing real repeat an announcement that
@@ -1457,6 +1489,7 @@ struct Decoder {
             op += run;
             if (RES) account_tokens(run, v, false);
             PZG_ACC(11, t_d);
+            }
         }
         // the queue moves up by v tokens
         LaneVec<uint32_t> SRC;
@@ -1470,23 +1503,25 @@ struct Decoder {
 
     // Fill the queue: 128-bit windows while at least 320 stream bits are ahead, then 64-bit ones.  Returns true when
     // the token at the cursor is one for token_step_checked() (a window said so, or too few bits are left for one).
+    template <bool FX>
     PZG_FN bool fill_queue()
     {
         do {
             if (__builtin_expect(br.window2_ok(), 1)) {
-                if (__builtin_expect(window_append2(), 0)) return true;
+                if (__builtin_expect(window_append2<FX>(), 0)) return true;
             } else {
-                if (!br.window_ok() || window_append()) return true;
+                if (!br.window_ok() || window_append<FX>()) return true;
             }
         } while (qn < QHIGH);
         return false;
     }
 
+    template <bool FX>
     PZG_FN int token_loop()
     {
         for (;;) {
             PZG_T0(tw);
-            const bool checked = qn < QHIGH && fill_queue();
+            const bool checked = qn < QHIGH && fill_queue<FX>();
             PZG_ACC(4, tw);
             if (!checked) {
                 PZG_T0(te);
@@ -1496,7 +1531,7 @@ struct Decoder {
                 continue;
             }
             PZG_T0(tc);
-            const int st = token_step_checked();
+            const int st = token_step_checked<FX>();
             PZG_ACC(5, tc);
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             prof[15] += 1;
@@ -1553,7 +1588,7 @@ struct Decoder {
         dist_n = 32u;
         if (uni(L.fixed_ready) == FIXED_MAGIC) {  // still there from an earlier block or stream of this wave
             lit_e15 = dist_e15 = 32768u;
-            use_sub = 1u;  // as build_table() left it when the tables were built (see below)
+            use_sub = FX_TABLES ? 0u : 1u;  // as it was left when the tables were built (see below)
             return;
         }
         const uint32_t lane = lane_id();
@@ -1562,13 +1597,17 @@ struct Decoder {
             const uint32_t s = s0 + lane;
             if (s < 320u) L.lens[s] = (uint8_t)(s <= 143u ? 8u : s <= 255u ? 9u : s <= 279u ? 7u : s <= 287u ? 8u : 5u);
         }
-        build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, &L.lit_meta, &lit_e15);
-        build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, &L.dist_meta, &dist_e15);
+        if (FX_TABLES) {  // one 2^9-entry literal/length table over both primary tables, a 2^5-entry distance table in the pool
+            build_table<9, TREE_LITLEN>(L.lens, 288u, L.lit_lut, &L.lit_meta, &lit_e15);
+            build_table<5, TREE_DIST>(L.lens + 288u, 32u, L.sub, &L.dist_meta, &dist_e15);
+            use_sub = 0u;
+        } else {
+            // (the resumable instance keeps the dynamic blocks' shape: use_sub = 1 from build_table(), the fixed code's 56
+            // long prefixes -- literals 144..255 are 9 bits -- go through the second-level tables)
+            build_table<LIT_BITS, TREE_LITLEN>(L.lens, 288u, L.lit_lut, &L.lit_meta, &lit_e15);
+            build_table<DIST_BITS, TREE_DIST>(L.lens + 288u, 32u, L.dist_lut, &L.dist_meta, &dist_e15);
+        }
         if (lane == 0u || PZG_WAVE == 1u) L.fixed_ready = FIXED_MAGIC;
-        // (use_sub = 1 from build_table(): the fixed code has 56 long prefixes -- literals 144..255 are 9 bits.  It
-        // is not a Huffman-optimal code, so how often they occur is up to the data: in plain text never, where the
-        // windows' second lookup costs 4 %; in binary data all the time, where leaving them to the checked path
-        // costs 7x.  The lookup stays on.)
         wave_sync();
     }
 
@@ -1905,7 +1944,7 @@ struct Decoder {
                 }
                 PZG_ACC(1, th);
                 PZG_T0(tt);
-                if (st == ST_OK) st = token_loop();
+                if (st == ST_OK) st = (FX_TABLES && btype == 1u) ? token_loop<FX_TABLES>() : token_loop<false>();
                 PZG_ACC(2, tt);
             }
             if (st != ST_OK) return st;
@@ -1938,7 +1977,7 @@ struct Decoder {
         for (;;) {
             int st;
             if (deferred == 0u) {
-                const bool checked = qn < QHIGH && fill_queue();
+                const bool checked = qn < QHIGH && fill_queue<false>();
                 if (!checked) {
                     const int se = emit_segment();
                     if (se == ST_OUT_FULL) {
@@ -1949,7 +1988,7 @@ struct Decoder {
                     continue;
                 }
                 const uint64_t tok_pos = stream_bit_pos();  // where the token about to be decoded starts
-                st = token_step_checked();
+                st = token_step_checked<false>();
                 if (st == ST_OK) continue;
                 if (truncated_suspends(st)) {
                     // the token is not all there yet: everything before it is decoded first, then the input is asked for

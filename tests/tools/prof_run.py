@@ -14,7 +14,13 @@ L.pzg_prof_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
 nstreams = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 datas = [corpus.zipf_text(size, i % 64) for i in range(64)]
-zs = [zlib.compress(d, 6) for d in datas]
+if len(sys.argv) > 3 and sys.argv[3] == "fixed":
+    zs = []
+    for d in datas:
+        co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        zs.append(co.compress(d) + co.flush())
+else:
+    zs = [zlib.compress(d, 6) for d in datas]
 streams = [zs[i % 64] for i in range(nstreams)]
 in_off = np.zeros(nstreams, np.uint64); out_off = np.zeros(nstreams, np.uint64)
 ip = op = 0
