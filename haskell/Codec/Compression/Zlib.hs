@@ -1,0 +1,295 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+
+-- |
+-- Drop-in replacement for pure-zlib's @Codec.Compression.Zlib@ (reference:
+-- @src\/Codec\/Compression\/Zlib.hs:3-8@) whose decoding runs on an MI355X through the C ABI of
+-- @include\/pzg.h@ (libpzg.so).  Same export list plus the batched 'decompressMany'.
+--
+-- NOT COMPILED IN THIS REPOSITORY: the build image has no GHC.  The file is complete -- a maintainer
+-- with GHC builds it unchanged against @include\/pzg.h@ with the cabal stanza in @haskell\/pzgpu.cabal@
+-- -- and every call it makes is exercised by the C++ and Python mirrors of the same module
+-- (@pure_zlib_amd\/cxx\/codec_compression_zlib.hpp@, @pure_zlib_amd\/zlib.py@, @incremental.py@),
+-- which ARE built and tested.  The types come from the reference's own
+-- @Codec.Compression.Zlib.Monad@, which stays in the package unchanged.
+module Codec.Compression.Zlib
+  ( DecompressionError (..)
+  , ZlibDecoder (NeedMore, Chunk, Done, DecompError)
+  , decompress
+  , decompressMany
+  , decompressIncremental
+  ) where
+
+import Codec.Compression.Zlib.Monad (DecompressionError (..), ZlibDecoder (..))
+import Control.Monad (forM, forM_, when)
+import Control.Monad.ST (ST)
+import Control.Monad.ST.Unsafe (unsafeIOToST)
+import Data.Bits (complement, (.&.))
+import qualified Data.ByteString as S
+import qualified Data.ByteString.Internal as SI
+import qualified Data.ByteString.Lazy as L
+import qualified Data.ByteString.Unsafe as SU
+import Data.IORef (IORef, newIORef, readIORef, writeIORef)
+import Data.Int (Int32)
+import Data.List (isPrefixOf)
+import Data.Word (Word32, Word64, Word8)
+import Foreign
+  ( FinalizerPtr, ForeignPtr, Ptr, alloca, allocaArray, allocaBytes, castPtr, copyBytes
+  , mallocForeignPtrBytes, newForeignPtr, nullPtr, peek, peekArray, plusPtr, poke, pokeArray, withForeignPtr )
+import Foreign.C.String (CString, peekCString)
+import Foreign.C.Types (CInt (..), CSize (..))
+import System.IO.Unsafe (unsafePerformIO)
+
+-- ---------------------------------------------------------------------------------------------
+-- The C ABI (include/pzg.h).  `safe`: the calls block for milliseconds; `unsafe` would stall the
+-- capability and the GC.
+
+data PzgCtx
+data PzgDecoder
+
+foreign import ccall safe "pzg_init_mask"
+  c_init_mask :: Word32 -> Ptr (Ptr PzgCtx) -> IO CInt
+
+foreign import ccall safe "pzg_decompress_many"
+  c_many
+    :: Ptr PzgCtx
+    -> Ptr Word8 -> Ptr Word64 -> Ptr Word64             -- in_base, in_off, in_len
+    -> Ptr Word8 -> Ptr Word64 -> Ptr Word64             -- out_base, out_off, out_cap
+    -> Ptr Word64 -> Ptr Int32 -> Ptr Word32             -- out_len, status, detail
+    -> Ptr Word64 -> Ptr Word32                          -- in_used, adler
+    -> Word32 -> Word32 -> IO CInt
+
+foreign import ccall unsafe "pzg_error_message"
+  c_msg :: Ptr Word8 -> Word64 -> Int32 -> Ptr Word32 -> CString -> CSize -> IO CInt
+
+foreign import ccall safe "pzg_decoder_create"
+  c_dec_create :: Ptr PzgCtx -> Word32 -> Ptr (Ptr PzgDecoder) -> IO CInt
+
+foreign import ccall unsafe "&pzg_decoder_destroy"
+  c_dec_destroy :: FinalizerPtr PzgDecoder
+
+foreign import ccall safe "pzg_decoder_feed"
+  c_dec_feed
+    :: Ptr PzgDecoder -> Ptr Word32 -> Word32
+    -> Ptr Word8 -> Ptr Word64 -> Ptr Word64 -> Ptr Word8   -- in_base, in_off, in_len, final_in
+    -> Ptr Word8 -> Ptr Word64 -> Ptr Word64                 -- out_base, out_off, out_cap
+    -> Ptr Word64 -> Ptr Int32 -> Ptr Word32 -> Ptr Word64   -- out_len, state, detail, in_used
+    -> Ptr Word32 -> Ptr Word32                              -- chunks, adler
+    -> IO CInt
+
+-- | One context per process over EVERY visible device (mask 0): a 'decompressMany' batch is
+-- partitioned over the GPUs of the node inside the library (SURVEY.md 8e; no collective).
+-- The library may be shared by threads; incremental decoders live on a one-device context.
+{-# NOINLINE theCtx #-}
+theCtx :: Ptr PzgCtx
+theCtx = unsafePerformIO (newCtx 0)
+
+{-# NOINLINE theDecoderCtx #-}
+theDecoderCtx :: Ptr PzgCtx
+theDecoderCtx = unsafePerformIO (newCtx 1)
+
+newCtx :: Word32 -> IO (Ptr PzgCtx)
+newCtx mask = alloca $ \pp -> do
+  rc <- c_init_mask mask pp
+  if rc /= 0
+    then error ("pzg_init_mask failed: " ++ show rc ++ " (libpzg has no CPU fallback)")
+    else peek pp
+
+-- ---------------------------------------------------------------------------------------------
+-- Status codes of include/pzg.h that this module looks at.
+
+stOk, stOutTooSmall, stNeedInput, stOutFull :: Int32
+stOk = 0
+stOutTooSmall = 14
+stNeedInput = 101
+stOutFull = 102
+
+-- | The reference's value for a (status, message) pair: `pzg_error_message` returns the exact
+-- `show` text (Monad.hs:95-102); the constructor follows from the status, the prefix is stripped.
+fromShowText :: Int32 -> String -> DecompressionError
+fromShowText st msg
+  | st == 1 || st == 15 = DecompressionError (strip "Decompression error: ")
+  | st >= 2 && st <= 4 = HeaderError (strip "Header error: ")
+  | st == 5 || st == 6 = FormatError (strip "Block format error: ")
+  | st >= 7 && st <= 9 = HuffmanTreeError (strip "Huffman tree manipulation error: ")
+  | st == 10 = ChecksumError (strip "Checksum error: ")
+  -- 11..13: inputs on which the reference THROWS (vector slice / array index out of range,
+  -- OutputWindow.hs:87, Deflate.hs:160-166, 199-205).  A strict drop-in throws as well.
+  | otherwise = error ("pure-zlib would have thrown here: " ++ msg)
+ where
+  strip p = if p `isPrefixOf` msg then drop (length p) msg else msg
+
+errorFor :: S.ByteString -> Int32 -> Ptr Word32 -> IO DecompressionError
+errorFor stream st pdet =
+  SU.unsafeUseAsCStringLen stream $ \(p, l) ->
+    allocaBytes 256 $ \buf -> do
+      _ <- c_msg (castPtr p) (fromIntegral l) st pdet buf 256
+      fromShowText st <$> peekCString buf
+
+-- | Zlib.hs:46-49: `Done` with whole unread CHUNKS left is "Finished with data remaining.";
+-- trailing bytes inside the last chunk that was handed over are ignored.
+chunkRule :: [S.ByteString] -> Word64 -> L.ByteString -> Either DecompressionError L.ByteString
+chunkRule chunks used out
+  | loaded < length chunks = Left (DecompressionError "Finished with data remaining.")
+  | otherwise = Right out
+ where
+  starts = scanl (+) 0 (map (fromIntegral . S.length) chunks) :: [Word64]
+  loaded = length (takeWhile (< used) (take (length chunks) starts))
+
+-- ---------------------------------------------------------------------------------------------
+
+-- | Drop-in for Zlib.hs:32: pure, strict, the same 'Left' values.
+decompress :: L.ByteString -> Either DecompressionError L.ByteString
+decompress ifile = case decompressMany [ifile] of
+  [r] -> r
+  _ -> error "decompressMany: one result per input"
+
+-- | New: every stream is decoded by its own wavefront, one launch per device.  zlib streams do not
+-- carry their decoded size: every stream gets a first capacity guess, and the ones that report
+-- PZG_E_OUT_TOO_SMALL (their exact size is in out_len) are decoded once more with it.
+decompressMany :: [L.ByteString] -> [Either DecompressionError L.ByteString]
+decompressMany inputs = unsafePerformIO $ do
+  let chunked = map (filter (not . S.null) . L.toChunks) inputs
+      flats = map S.concat chunked
+      caps0 = map (\b -> max 256 (4 * S.length b)) flats
+  first <- launch flats caps0
+  -- second pass: only the streams whose capacity was too small
+  let need = [ (i, fromIntegral len) | (i, (st, len, _, _, _)) <- zip [0 :: Int ..] first, st == stOutTooSmall ]
+  second <- if null need then return [] else launch [ flats !! i | (i, _) <- need ] (map snd need)
+  let redo = zip (map fst need) second
+      pick i r = maybe r id (lookup i redo)
+  forM (zip3 [0 ..] chunked flats) $ \(i, chunks, flat) -> do
+    let (st, _len, used, out, det) = pick i (first !! i)
+    if st == stOk
+      then return (chunkRule chunks used (L.fromStrict out))
+      else Left <$> (allocaArray 2 $ \pdet -> pokeArray pdet [fst det, snd det] >> errorFor flat st pdet)
+
+-- | One pzg_decompress_many call on host buffers.  Per stream: (status, out_len, in_used, bytes, detail).
+launch :: [S.ByteString] -> [Int] -> IO [(Int32, Word64, Word64, S.ByteString, (Word32, Word32))]
+launch flats caps = do
+  let n = length flats
+      align16 x = (x + 15) .&. complement 15
+      ilens = map S.length flats
+      ioffs = scanl (\o l -> o + align16 l) 0 ilens
+      ooffs = scanl (\o c -> o + align16 c) 0 caps
+  inBuf <- mallocForeignPtrBytes (last ioffs + 16) :: IO (ForeignPtr Word8)
+  outBuf <- mallocForeignPtrBytes (last ooffs + 16) :: IO (ForeignPtr Word8)
+  withForeignPtr inBuf $ \pin -> withForeignPtr outBuf $ \pout ->
+    allocaArray n $ \pioff -> allocaArray n $ \pilen -> allocaArray n $ \pooff -> allocaArray n $ \pocap ->
+    allocaArray n $ \polen -> allocaArray n $ \pst -> allocaArray (2 * n) $ \pdet -> allocaArray n $ \pused -> do
+      forM_ (zip flats ioffs) $ \(b, o) ->
+        SU.unsafeUseAsCStringLen b $ \(p, l) -> when (l > 0) $ copyBytes (pin `plusPtr` o) (castPtr p) l
+      pokeArray pioff (map fromIntegral (take n ioffs))
+      pokeArray pilen (map fromIntegral ilens)
+      pokeArray pooff (map fromIntegral (take n ooffs))
+      pokeArray pocap (map fromIntegral caps)
+      rc <- c_many theCtx pin pioff pilen pout pooff pocap polen pst pdet pused nullPtr (fromIntegral n) 0
+      when (rc /= 0) $ error ("pzg_decompress_many failed: " ++ show rc)
+      sts <- peekArray n pst
+      lens <- peekArray n polen
+      useds <- peekArray n pused
+      dets <- peekArray (2 * n) pdet
+      forM (zip [0 ..] (zip3 sts lens useds)) $ \(i, (st, len, used)) -> do
+        let cap = caps !! i
+            nb = if st == stOk then fromIntegral len else 0 :: Int
+        out <- SI.create (min nb cap) $ \d -> copyBytes d (pout `plusPtr` (ooffs !! i)) (min nb cap)
+        return (st, len, used, out, (dets !! (2 * i), dets !! (2 * i + 1)))
+
+-- ---------------------------------------------------------------------------------------------
+-- decompressIncremental (Zlib.hs:29-30) and the ZlibDecoder protocol (Monad.hs:163-197): the
+-- suspended decoder lives on the device; a feed is one launch that continues it, and the chunks
+-- come out exactly when the reference publishes them (moveWindow, Monad.hs:338-347).
+
+data Inc = Inc
+  { incDec :: ForeignPtr PzgDecoder
+  , incTail :: IORef S.ByteString      -- input the decoder has not consumed yet
+  , incAll :: IORef S.ByteString       -- the whole input so far (only for the exact HuffmanTreeError text)
+  , incPending :: IORef S.ByteString   -- delivered bytes not yet published as chunks
+  , incPublished :: IORef Word32       -- chunks published so far
+  }
+
+data Ending = EndNeedMore | EndDone | EndError DecompressionError
+
+excessChunk, feedRoom :: Int
+excessChunk = 32768     -- OutputWindow.hs:42-43 excessChunkSize
+feedRoom = 256 * 1024   -- output room per launch
+
+decompressIncremental :: ST s (ZlibDecoder s)
+decompressIncremental = unsafeIOToST $ do
+  pd <- alloca $ \pp -> do
+    rc <- c_dec_create theDecoderCtx 1 pp
+    when (rc /= 0) $ error ("pzg_decoder_create failed: " ++ show rc)
+    peek pp
+  inc <- Inc <$> newForeignPtr c_dec_destroy pd <*> newIORef S.empty <*> newIORef S.empty
+             <*> newIORef S.empty <*> newIORef 0
+  return (NeedMore (feedInc inc))   -- runDeflateM starts with no input (Monad.hs:172-179)
+
+-- | NeedMore's continuation (Monad.hs:185-197 loadChunk).
+feedInc :: Inc -> S.ByteString -> ST s (ZlibDecoder s)
+feedInc inc chunk
+  | S.null chunk = return (NeedMore (feedInc inc))   -- S.uncons = Nothing: ask again
+  | otherwise = unsafeIOToST $ do
+      t <- readIORef (incTail inc)
+      writeIORef (incTail inc) (t `S.append` chunk)
+      a <- readIORef (incAll inc)
+      writeIORef (incAll inc) (a `S.append` chunk)
+      (chunksNow, ending) <- continueDecoder inc
+      publish inc chunksNow ending
+
+-- | Launch until the decoder wants input, has finished or has failed (a launch that runs out of
+-- output room is repeated with the rest of the input).  Returns the reference's chunk count.
+continueDecoder :: Inc -> IO (Word32, Ending)
+continueDecoder inc = do
+  t <- readIORef (incTail inc)
+  out <- mallocForeignPtrBytes feedRoom :: IO (ForeignPtr Word8)
+  (st, produced, used, chunks, det) <-
+    withForeignPtr (incDec inc) $ \pd -> withForeignPtr out $ \pout ->
+    SU.unsafeUseAsCStringLen t $ \(pin, tlen) ->
+    alloca $ \pioff -> alloca $ \pilen -> alloca $ \pooff -> alloca $ \pocap -> alloca $ \polen ->
+    alloca $ \pst -> allocaArray 2 $ \pdet -> alloca $ \pused -> alloca $ \pchunks -> do
+      poke pioff 0
+      poke pilen (fromIntegral tlen)
+      poke pooff 0
+      poke pocap (fromIntegral feedRoom)
+      rc <- c_dec_feed pd nullPtr 1 (castPtr pin) pioff pilen nullPtr pout pooff pocap polen pst pdet pused pchunks nullPtr
+      when (rc /= 0) $ error ("pzg_decoder_feed failed: " ++ show rc)
+      st <- peek pst
+      len <- peek polen
+      used <- peek pused
+      ch <- peek pchunks
+      d <- peekArray 2 pdet
+      bytes <- SI.create (fromIntegral len) $ \dst -> copyBytes dst pout (fromIntegral len)
+      return (st, bytes, used, ch, d)
+  p <- readIORef (incPending inc)
+  writeIORef (incPending inc) (p `S.append` produced)
+  writeIORef (incTail inc) (S.drop (fromIntegral used) t)
+  if st == stOutFull
+    then continueDecoder inc
+    else if st == stNeedInput
+      then return (chunks, EndNeedMore)
+      else if st == stOk
+        then return (chunks, EndDone)
+        else do
+          whole <- readIORef (incAll inc)
+          e <- allocaArray 2 $ \pdet -> pokeArray pdet det >> errorFor whole st pdet
+          return (chunks, EndError e)
+
+-- | The constructors the reference goes through from here: one Chunk of 32,768 bytes for every
+-- chunk moveWindow has published since the last feed, then NeedMore / the rest + Done / the error.
+publish :: Inc -> Word32 -> Ending -> IO (ZlibDecoder s)
+publish inc chunksNow ending = do
+  done <- readIORef (incPublished inc)
+  if done < chunksNow
+    then do
+      p <- readIORef (incPending inc)
+      let (c, rest) = S.splitAt excessChunk p
+      writeIORef (incPending inc) rest
+      writeIORef (incPublished inc) (done + 1)
+      return (Chunk c (unsafeIOToST (publish inc chunksNow ending)))
+    else case ending of
+      EndNeedMore -> return (NeedMore (feedInc inc))
+      EndError e -> return (DecompError e)
+      EndDone -> do
+        -- finalize (Monad.hs:349-353): whatever is left in the window, as one chunk, then Done
+        p <- readIORef (incPending inc)
+        writeIORef (incPending inc) S.empty
+        return (Chunk p (return Done))
