@@ -1506,12 +1506,14 @@ struct Decoder {
     template <bool FX>
     PZG_FN bool fill_queue()
     {
+        // the hot loop proper: nothing but 128-bit windows
+        while (__builtin_expect(br.window2_ok(), 1)) {
+            if (__builtin_expect(window_append2<FX>(), 0)) return true;
+            if (qn >= QHIGH) return false;
+        }
+        // the last 320 bits of the stream
         do {
-            if (__builtin_expect(br.window2_ok(), 1)) {
-                if (__builtin_expect(window_append2<FX>(), 0)) return true;
-            } else {
-                if (!br.window_ok() || window_append<FX>()) return true;
-            }
+            if (!br.window_ok() || window_append<FX>()) return true;
         } while (qn < QHIGH);
         return false;
     }
