@@ -53,7 +53,8 @@ extern "C" {
 #define PZG_E_FMT_LEN_NLEN        5  /* FormatError "Len/nlen mismatch in uncompressed block."    Deflate.hs:75-76 */
 #define PZG_E_FMT_BTYPE           6  /* FormatError "Unacceptable BTYPE: 3"                       Deflate.hs:102-104 */
 #define PZG_E_HUFF_BUILD          7  /* HuffmanTreeError <insert message>; d0 = tree id, d1 = bit offset of the block header
-                                        (pzg_error_message re-derives the exact text)             HuffmanTree.hs:55-63 */
+                                        modulo 2^32 (pzg_error_message re-derives the exact text from it: exact for streams
+                                        with less than 512 MiB of compressed data in front of the block)  HuffmanTree.hs:55-63 */
 #define PZG_E_HUFF_EMPTY_TREE     8  /* HuffmanTreeError "Tried to advance empty tree!"           HuffmanTree.hs:76 */
 #define PZG_E_HUFF_EMPTY_BRANCH   9  /* HuffmanTreeError "Advanced to empty tree!"                HuffmanTree.hs:80 */
 #define PZG_E_CHECKSUM           10  /* ChecksumError "checksum mismatch: <hex d0> != <hex d1>"   Deflate.hs:56-63 */
