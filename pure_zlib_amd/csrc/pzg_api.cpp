@@ -65,8 +65,16 @@ public:
         }
         std::vector<std::thread> th;
         th.reserve(parts - 1);
-        for (unsigned t = 1; t < parts; ++t) th.emplace_back([&f, t, parts] { f(t, parts); });
+        unsigned started = 1;
+        for (; started < parts; ++started) {
+            try {
+                th.emplace_back([&f, started, parts] { f(started, parts); });
+            } catch (...) {  // no more threads to be had: the caller does the remaining parts itself
+                break;
+            }
+        }
         f(0u, parts);
+        for (unsigned t = started; t < parts; ++t) f(t, parts);
         for (auto &x : th) x.join();
     }
 
