@@ -26,6 +26,7 @@
 //
 // The same source compiles as a host program for the CPU model tests (see wave.h).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include "wave.h"
@@ -39,6 +40,12 @@
 #define PZG_T0(var)
 #define PZG_ACC(slot, var)
 #define PZG_ACCW(slot, var)
+#endif
+// Diagnostic build only (-DPZG_MARKS): named comments in the device assembly (tests/tools/asm_regions.py counts between them)
+#if defined(PZG_MARKS) && PZG_DEVICE_PASS
+#define PZG_MARK(name) asm volatile("; ##MARK " name)
+#else
+#define PZG_MARK(name)
 #endif
 
 namespace pzg {
@@ -100,7 +107,7 @@ constexpr int MAX_LENS = 288 + 32 + 138;
 //     distance base   [4:0] n + extra bits [12:8] n      [31:16] base distance
 //     code-length sym [4:0] n              [12:8] extra bits          [31:16] symbol (dynamic_header only)
 //   stoppers (bit 7 set): a window's walk ends there and token_step_checked() takes over
-//     [4:0] n  [7] 1  [11:8] kind  [30:16] value
+//     [4:0] n  [7] 1  [11:8] kind  [29:16] value  [30] 1 for K_SUB only (the only entries >= 2^30 as signed numbers)
 enum : uint32_t {
     K_LIT = 0,           // (token entry, bit 31 clear) literal byte or code-length symbol
     K_BASE = 1,          // (token entry) base length (bit 31 set) / base distance, extra bits follow
@@ -113,12 +120,14 @@ enum : uint32_t {
 };
 constexpr uint32_t ENT_STOP = 0x80u;  // bit 7: the byte sum tb of spec_finish() is then >= 128, which the walk tests for
 constexpr uint32_t ENT_MATCH = 0x80000000u;
+constexpr uint32_t ENT_SUB = 0x40000000u;  // K_SUB entries: found by ONE signed compare in the windows' decode
 
 PZG_FN uint32_t mk_stop(uint32_t n, uint32_t kind, uint32_t value) { return n | ENT_STOP | (kind << 8) | (value << 16); }
 PZG_FN bool ent_is_stop(uint32_t x) { return (x & ENT_STOP) != 0u; }
 PZG_FN uint32_t ent_stop_kind(uint32_t x) { return (x >> 8) & 15u; }   // stoppers only
 PZG_FN uint32_t ent_n(uint32_t x) { return x & 31u; }                   // stoppers, literals, code-length symbols
-PZG_FN uint32_t ent_val(uint32_t x) { return x >> 16; }                 // stoppers (value), distance base, code-length symbol
+PZG_FN uint32_t ent_val(uint32_t x) { return x >> 16; }                 // stoppers but K_SUB (value), distance base, code-length symbol
+PZG_FN uint32_t ent_sub_index(uint32_t x) { return (x >> 16) & 0xffu; } // K_SUB: first entry of the second-level table in the pool
 PZG_FN uint32_t ent_base_n(uint32_t x) { return (x >> 8) & 31u; }       // length / distance base: code bits
 PZG_FN uint32_t ent_base_tot(uint32_t x) { return x & 31u; }            // ... code bits + extra bits
 PZG_FN uint32_t ent_len_base(uint32_t x) { return (x >> 16) & 511u; }   // length base
@@ -424,6 +433,8 @@ struct Decoder {
     // A segment's bytes from literals and the near ring are stored at once; bytes whose source is older than
     // the ring ("far") are requested from HBM/L2 and stored only when the next segment starts (complete_pending),
     // so the far-read latency overlaps the decode of the next windows instead of stalling the wave.
+    const uint8_t *far_base;    // far reads: far_base + 32768 is produced-byte `flushed` (or the input, see set_far_base)
+    uint64_t far_okmask;        // all ones while far reads may touch the output (flushed < cap), else 0
     uint64_t pend_m0, pend_m1;  // lanes of the last segment's two 64-byte passes whose byte is still on its way (0 = none)
     uint32_t pend_pos;          // those bytes belong at ring position pend_pos + 64 * pass + lane
     LaneVec<uint8_t> pendF0, pendF1;   // the far bytes (valid in the lanes of pend_m0 / pend_m1); bytes, so that nothing
@@ -474,6 +485,7 @@ struct Decoder {
         pend_m1 = uni64(pend_m1);
         pend_pos = uni(pend_pos);
         hist_extra = uni(hist_extra);
+        far_okmask = uni64(far_okmask);
         qn = uni(qn);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
@@ -568,8 +580,19 @@ struct Decoder {
         adler_a = (uint32_t)(((uint64_t)adler_a + sum_a) % ADLER_MOD);
         adler_b = (uint32_t)(nb % ADLER_MOD);
         flushed = to;
+        set_far_base();
         wave_sync();
         PZG_ACC(3, tf);
+    }
+    // Far sources lie below `flushed`, so inside the capacity while `flushed` is; a stream that has outgrown its capacity
+    // is redone by the 32 KiB-ring kernel anyway (its far bytes were never stored): it reads its input instead.
+    // Recomputed per flush (every KiB or so), not per segment.
+    PZG_FN void set_far_base()
+    {
+        if (!HYBRID) return;
+        const bool ok = flushed < cap;
+        far_base = ok ? out + (flushed - 32768u) : in - 32768;
+        far_okmask = ok ? ~0ull : 0ull;
     }
 
     // store the last segment's far bytes (see pend_m0), then flush if due: from here on every byte below `op` is in the ring
@@ -585,12 +608,12 @@ struct Decoder {
 #endif
             if (pend_m0 != 0ull) {
                 PZG_LANES_BEGIN(j)
-                    sel_store(lane_bit(pend_m0, j), &L.ring[(pend_pos + j) & RMASK], PZG_LV(pendF0, j), j);
+                    ring_store(lane_bit(pend_m0, j), ((pend_pos + j)) & RMASK, PZG_LV(pendF0, j), j);
                 PZG_LANES_END
             }
             if (pend_m1 != 0ull) {
                 PZG_LANES_BEGIN(j)
-                    sel_store(lane_bit(pend_m1, j), &L.ring[(pend_pos + 64u + j) & RMASK], PZG_LV(pendF1, j), j);
+                    ring_store(lane_bit(pend_m1, j), ((pend_pos + 64u + j)) & RMASK, PZG_LV(pendF1, j), j);
                 PZG_LANES_END
             }
             pend_m0 = pend_m1 = 0ull;
@@ -611,6 +634,14 @@ struct Decoder {
     {
         uint8_t *p = pred ? dst : &L.dump[lane & 63u];
         *p = v;
+    }
+    // the same into the ring at index `idx` (already reduced modulo RING): the select is made on the offset from the
+    // ring's base, so the base itself rides in the store's immediate offset (one vector instruction less per store)
+    PZG_FN void ring_store(bool pred, uint32_t idx, uint8_t v, uint32_t lane)
+    {
+        constexpr uint32_t DUMP_REL = (uint32_t)(offsetof(WaveLds<RING_BITS>, dump) - offsetof(WaveLds<RING_BITS>, ring));
+        uint8_t *base = L.ring;
+        base[pred ? idx : DUMP_REL + lane] = v;  // lane < 64 (the dump has room for 76)
     }
 
     // The byte `back` positions before the output cursor (1 <= back <= 32768, back <= op).
@@ -646,7 +677,7 @@ struct Decoder {
     PZG_FN void put_literal(uint32_t v)
     {
         const uint32_t lane = lane_id();
-        sel_store(lane == 0u, &L.ring[(uint32_t)op & RMASK], (uint8_t)v, lane);
+        ring_store(lane == 0u, ((uint32_t)op) & RMASK, (uint8_t)v, lane);
         op++;
     }
 
@@ -668,7 +699,7 @@ struct Decoder {
                     v = far ? fetch_far(far, dist - lane) : v;
                 }
             }
-            sel_store(lane < len, &L.ring[(dst0 + lane) & RMASK], v, lane);
+            ring_store(lane < len, ((dst0 + lane)) & RMASK, v, lane);
             op += len;
             return;
         }
@@ -705,7 +736,7 @@ struct Decoder {
 #pragma unroll
         for (uint32_t c = 0; c < MAXCH; ++c) {
             const uint32_t k = c * PZG_WAVE + lane;
-            if (c * PZG_WAVE < len) sel_store(k < len, &L.ring[(dst0 + k) & RMASK], v[c], lane);
+            if (c * PZG_WAVE < len) ring_store(k < len, ((dst0 + k)) & RMASK, v[c], lane);
         }
         op += len;
     }
@@ -799,7 +830,7 @@ struct Decoder {
                 if (e15 == 0u) {
                     ent = mk_stop(1, K_EMPTY_TREE, 0);
                 } else if ((c_p << (15u - P)) < e15) {
-                    ent = (TREE != TREE_CODELEN && c_p - covered_p < np_fit) ? mk_stop(sb, K_SUB, sub0 + ((c_p - covered_p) << sb))
+                    ent = (TREE != TREE_CODELEN && c_p - covered_p < np_fit) ? (mk_stop(sb, K_SUB, sub0 + ((c_p - covered_p) << sb)) | ENT_SUB)
                                                                            : mk_stop(0, K_LONG, 0);
                 } else {
                     uint32_t d = (uint32_t)P;  // smallest d whose d-bit prefix is at or past the end of all codes
@@ -960,7 +991,7 @@ struct Decoder {
         uint32_t e = uni(lit_table<FX>()[bits & ((1u << lit_bits<FX>()) - 1u)]);
         uint32_t kind = ent_kind_lit(e);
         if (kind == K_SUB) {  // second level: one more (wave-uniform) lookup
-            e = uni(L.sub[ent_val(e) + ((bits >> LIT_BITS) & ((1u << ent_n(e)) - 1u))]);
+            e = uni(L.sub[ent_sub_index(e) + ((bits >> LIT_BITS) & ((1u << ent_n(e)) - 1u))]);
             kind = ent_kind_lit(e);
         }
         if (kind == K_LONG) {  // the exact walk for whatever the tables do not hold
@@ -983,7 +1014,7 @@ struct Decoder {
             uint32_t d = uni(dist_table<FX>()[bits & ((1u << dist_bits<FX>()) - 1u)]);
             uint32_t dk = ent_kind_dist(d);
             if (dk == K_SUB) {
-                d = uni(L.sub[ent_val(d) + ((bits >> DIST_BITS) & ((1u << ent_n(d)) - 1u))]);
+                d = uni(L.sub[ent_sub_index(d) + ((bits >> DIST_BITS) & ((1u << ent_n(d)) - 1u))]);
                 dk = ent_kind_dist(d);
             }
             if (dk == K_LONG) {
@@ -1041,13 +1072,12 @@ struct Decoder {
     }
     PZG_FN void spec_sub(Spec &t)
     {
-        const bool is_sub = (t.e & (ENT_STOP | (15u << 8))) == (ENT_STOP | ((uint32_t)K_SUB << 8));
-        uint32_t i2 = is_sub ? ent_val(t.e) + ((t.w_lo >> LIT_BITS) & ((1u << ent_n(t.e)) - 1u)) : 0u;
-#if PZG_DEVICE_PASS
-        asm("" : "+v"(i2));  // every lane looks up (entry 0 where there is nothing to): no EXEC narrowing, no branch around the load
-#endif
-        const uint32_t e2 = L.sub[i2];
-        t.e = is_sub ? e2 : t.e;
+        // four vector instructions: compare, bit field, add, shift; the lookup itself runs under the compare's mask
+        // (the entry's bits 14, 15 are clear: (e >> 14) & 0x3fc is the table's byte offset in the pool)
+        if ((int32_t)t.e >= (int32_t)ENT_SUB) {
+            const uint32_t off = ((t.e >> 14) & 0x3fcu) + (ubfe(t.w_lo, LIT_BITS, t.e) << 2);
+            t.e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.sub) + off);
+        }
     }
     template <bool FX>
     PZG_FN void spec_dist(Spec &t)
@@ -1066,8 +1096,8 @@ struct Decoder {
         const uint32_t xd = ubfe(t.w2, dn, d - dn);           // distance extra bits
         const uint32_t tk_match = hi_halves(e, d) + ((xl << 16) + xd);  // TK_MATCH | (base len + xl) << 16 | (base dist + xd): no carries
         const uint32_t m = (uint32_t)((int32_t)e >> 31);      // all ones: a length entry, the distance entry counts
-        tb = (e + (d & m)) & 0xffu;                           // byte sums: either stop bit (0x80) pushes it to >= 128
-        tk = (tk_match & m) | (e & ~m);
+        tb = (e & 0xffu) + ((d & m) & 0xffu);                 // byte sum (one SDWA add): either stop bit (0x80) makes it >= 128
+        tk = bit_select(m, tk_match, e);
     }
     template <bool FX>
     PZG_FN void decode_at(uint32_t lo, uint32_t mid, uint32_t hi, uint32_t r, uint32_t &tb, uint32_t &tk)
@@ -1212,6 +1242,7 @@ struct Decoder {
     template <bool FX>
     PZG_FN bool window_append2()
     {
+        PZG_MARK("w2.begin");
         LaneVec<uint32_t> TB0, TK0, TB1, TK1;
 #if PZG_DEVICE_PASS
         {
@@ -1253,6 +1284,7 @@ struct Decoder {
         // ---- the walk: first half, and unless it ended at a stopper, the second -------------------------
         // The common case is written straight through (no flags to merge): both halves walked, no stopper, the queue
         // takes every token.  Anything else goes through window2_rare().
+        PZG_MARK("w2.walk");
         uint64_t S0 = 0, S1 = 0;
         const uint32_t k0 = walk_half(TB0, 0u, S0);  // where the chain enters the second half (64 or more: a stopper)
         if (__builtin_expect(k0 < 64u, 1)) {
@@ -1260,8 +1292,11 @@ struct Decoder {
             if (__builtin_expect(k1 < 64u, 1)) {
                 const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
                 if (__builtin_expect(qn + nt0 + nt1 <= QCAP, 1)) {
+        PZG_MARK("w2.append");
                     queue_append(TK0, S0, nt0, TK1, S1, nt1);
+        PZG_MARK("w2.drop");
                     br.drop_short(k1 + 128u);
+        PZG_MARK("w2.end");
                     return false;
                 }
             }
@@ -1326,31 +1361,35 @@ struct Decoder {
     {
         LaneVec<uint32_t> PJ;
         lanes_gather(PJ, QT, TOK);
-        LaneVec<bool> FAR;
+        LaneVec<bool> INSIDE, MATCH, OLD;
         PZG_LANES_BEGIN(j)
             const uint32_t pj = PZG_LV(PJ, j), o = o0 + j, dist = pj & 0xffffu;
             const bool is_match = (int32_t)pj < 0;
             const uint8_t g = L.ring[(op32 + o - dist) & RMASK];
             PZG_LV(VAL, j) = is_match ? (uint32_t)g : ((pj >> 8) & 0xffu);
             PZG_LV(DIST, j) = dist;
-            PZG_LV(FAR, j) = HYBRID & (o < run) & is_match & (dist - o > RING);
+            PZG_LV(INSIDE, j) = o < run;
+            PZG_LV(MATCH, j) = is_match;
+            PZG_LV(OLD, j) = dist - o > RING;
         PZG_LANES_END
-        return HYBRID ? lanes_ballot(FAR) : 0ull;
+        // (one ballot per compare and the masks combined by scalar instructions: a ballot of a compound predicate costs
+        // two more vector instructions)
+        return HYBRID ? (lanes_ballot(INSIDE) & lanes_ballot(MATCH) & lanes_ballot(OLD)) : 0ull;
     }
     // ... the stores: at once for the lanes that have their byte; the far lanes' bytes are requested and left pending.
     // The far request is ONE unconditional load per pass, straight-line (a load inside a branch makes the compiler merge
     // its result with the old register -- a copy that waits for the load on the spot): base + 32-bit lane offset, lanes
     // with no far source re-read a byte that is there anyway.
     PZG_FN void segment_store(uint32_t o0, uint32_t run, uint32_t op32, const LaneVec<uint32_t> &VAL, const LaneVec<uint32_t> &DIST,
-                              uint64_t farm, const uint8_t *far_base, bool far_ok, LaneVec<uint8_t> &pendF)
+                              uint64_t farm, uint32_t fdelta, LaneVec<uint8_t> &pendF)
     {
         PZG_LANES_BEGIN(j)
             const uint32_t o = o0 + j;
-            sel_store((o < run) & !lane_bit(farm, j), &L.ring[(op32 + o) & RMASK], (uint8_t)PZG_LV(VAL, j), j);
+            ring_store((o < run) & !lane_bit(farm, j), (op32 + o) & RMASK, (uint8_t)PZG_LV(VAL, j), j);
         PZG_LANES_END
-        if (HYBRID) {  // sources older than the ring: the stream's own flushed output
+        if (HYBRID) {  // sources older than the ring: the stream's own flushed output (fdelta = op - flushed)
             PZG_LANES_BEGIN(j)
-                const uint32_t off = (far_ok & lane_bit(farm, j)) ? 32768u + (o0 + j) - PZG_LV(DIST, j) : 32768u;
+                const uint32_t off = lane_bit(farm, j) ? 32768u + fdelta + (o0 + j) - PZG_LV(DIST, j) : 32768u;
 #if PZG_DEVICE_PASS
                 PZG_LV(pendF, j) = __builtin_nontemporal_load(far_base + off);
 #else
@@ -1359,6 +1398,7 @@ struct Decoder {
             PZG_LANES_END
         }
     }
+
 
     // Resumable instance: the reference publishes its output in 32 KiB chunks -- moveWindow (Monad.hs:338-347) runs after
     // every match and at every block end and hands out ONE chunk when the window holds 64 KiB or more
@@ -1390,16 +1430,18 @@ struct Decoder {
     }
     PZG_FN int emit_segment()
     {
+        PZG_MARK("e.begin");
         PZG_T0(t_a);
         complete_pending();  // the previous segment's bytes must all be in the ring from here on
         PZG_ACCW(8, t_a);
         if (RES && op + 512u > cap) return ST_OUT_FULL;  // (resumable: never produce past this call's output room)
+        PZG_MARK("e.scan");
         PZG_T0(t_b);
         // bytes of history a distance may reach back over; dist <= 32768, so a clamp is enough (scalar shift + test)
         const uint32_t hist = (op >> 20) ? 0x100000u : (uint32_t)op + (RING_BITS == 15 ? hist_extra : 0u);
         const uint32_t op32 = (uint32_t)op;
         LaneVec<uint32_t> INCL, START;
-        LaneVec<bool> STOP;
+        LaneVec<bool> BIG, MATCH, SRC_IN, SRC_OUT;
         PZG_LANES_BEGIN(t)
             PZG_LV(INCL, t) = t < qn ? ((PZG_LV(QT, t) >> 16) & 511u) : 0u;
         PZG_LANES_END
@@ -1407,13 +1449,18 @@ struct Decoder {
         PZG_LANES_BEGIN(t)
             const uint32_t tk = PZG_LV(QT, t), lout = (tk >> 16) & 511u, dist = tk & 0xffffu;
             const uint32_t endb = PZG_LV(INCL, t), start = endb - lout;
-            const bool is_match = (int32_t)tk < 0;
             PZG_LV(START, t) = start;
-            // (bitwise, not short-circuit: one straight-line predicate instead of a lane-dependent branch)
-            PZG_LV(STOP, t) = (t < qn) & ((endb > SEG) | (is_match & ((dist < endb) | (dist > hist + start))));
+            PZG_LV(BIG, t) = endb > SEG;                 // does not fit the segment
+            PZG_LV(MATCH, t) = (int32_t)tk < 0;
+            PZG_LV(SRC_IN, t) = dist < endb;              // a match whose source is not complete before the segment starts
+            PZG_LV(SRC_OUT, t) = dist > hist + start;     // ... or lies before the output (an error: found when it heads a segment)
         PZG_LANES_END
-        const uint64_t stopmask = lanes_ballot(STOP);
+        // (four compares, the rest on the masks: scalar instructions instead of select / or / compare chains per lane)
+        const uint64_t waiting = (1ull << qn) - 1ull;  // qn <= 63
+        const uint64_t stopmask =
+            waiting & (lanes_ballot(BIG) | (lanes_ballot(MATCH) & (lanes_ballot(SRC_IN) | lanes_ballot(SRC_OUT))));
         uint32_t v = stopmask ? ctz64(stopmask) : qn;  // tokens of this segment
+        PZG_MARK("e.v");
         PZG_ACCW(9, t_b);
         if (v == 0u) {
             const uint32_t tk = lane_get(QT, 0u), dist = tk & 0xffffu, len = (tk >> 16) & 511u;
@@ -1435,7 +1482,7 @@ struct Decoder {
                 // one byte per token: nothing but literals (a match is three bytes or more).  Byte j IS token j's byte:
                 // no announcements, no gathers -- literal-heavy data (little or no redundancy) spends its time here.
                 PZG_LANES_BEGIN(j)
-                    sel_store(j < v, &L.ring[(op32 + j) & RMASK], (uint8_t)(PZG_LV(QT, j) >> 8), j);
+                    ring_store(j < v, ((op32 + j)) & RMASK, (uint8_t)(PZG_LV(QT, j) >> 8), j);
                 PZG_LANES_END
                 op += run;
                 if (RES) ow += run;  // (no match: no moveWindow check)
@@ -1447,6 +1494,7 @@ struct Decoder {
             // is made anyway -- token 0's at lane 0 in the first pass, the last token's in the second -- so colliding
             // writes all carry the same value.
             LaneVec<uint32_t> ONE, DEST, MARK, TOK, VAL0, VAL1, DIST0, DIST1;
+        PZG_MARK("e.general");
             PZG_LANES_BEGIN(t)
                 PZG_LV(DEST, t) = ((t < v) & (PZG_LV(START, t) < 64u)) ? PZG_LV(START, t) : 0u;
                 PZG_LV(ONE, t) = 1u;
@@ -1456,7 +1504,9 @@ struct Decoder {
             PZG_LANES_BEGIN(j)
                 PZG_LV(TOK, j) = mbcnt_k(starts0 >> 1, j);  // announcements at offsets 1 .. j
             PZG_LANES_END
-            const uint64_t farm0 = segment_gather(TOK, 0u, run, op32, VAL0, DIST0);
+        PZG_MARK("e.gather0");
+            uint64_t farm0 = segment_gather(TOK, 0u, run, op32, VAL0, DIST0);
+        PZG_MARK("e.pass1");
             uint64_t farm1 = 0ull;
             if (run > 64u) {
                 const uint32_t start_last = lane_get(START, v - 1u);
@@ -1475,14 +1525,15 @@ struct Decoder {
                 PZG_LANES_END
                 farm1 = segment_gather(TOK, 64u, run, op32, VAL1, DIST1);
             }
+        PZG_MARK("e.store");
             // both gathers precede the stores: the first pass' bytes replace ring bytes the second may still read
-            // Far sources lie below op, so inside the capacity while op is; a stream that has outgrown its capacity is
-            // redone by the 32 KiB-ring kernel anyway (its far bytes were never stored): it reads its input instead.
-            const bool far_ok = op < cap;
-            const uint8_t *far_base = far_ok ? out + (op - 32768u) : in - 32768;
+            farm0 &= far_okmask;
+            farm1 &= far_okmask;
+            const uint32_t fdelta = (uint32_t)(op - flushed);
             if (HYBRID && (farm0 | farm1) != 0ull) far_fence();
-            segment_store(0u, run, op32, VAL0, DIST0, farm0, far_base, far_ok, pendF0);
-            if (run > 64u) segment_store(64u, run, op32, VAL1, DIST1, farm1, far_base, far_ok, pendF1);
+            segment_store(0u, run, op32, VAL0, DIST0, farm0, fdelta, pendF0);
+            if (run > 64u) segment_store(64u, run, op32, VAL1, DIST1, farm1, fdelta, pendF1);
+        PZG_MARK("e.stored");
             pend_m0 = farm0;
             pend_m1 = farm1;
             pend_pos = op32;
@@ -1491,12 +1542,14 @@ struct Decoder {
             PZG_ACC(11, t_d);
             }
         }
+        PZG_MARK("e.shift");
         // the queue moves up by v tokens
         LaneVec<uint32_t> SRC;
         PZG_LANES_BEGIN(j)
             PZG_LV(SRC, j) = j + v;
         PZG_LANES_END
         lanes_gather(QT, QT, SRC);
+        PZG_MARK("e.end");
         qn -= v;
         return ST_OK;
     }
@@ -1571,7 +1624,7 @@ struct Decoder {
             for (uint32_t k0 = 0; k0 < piece; k0 += PZG_WAVE) {
                 const uint32_t k = k0 + lane;
                 const uint8_t v = in[p + done + (k < piece ? k : piece - 1u)];
-                sel_store(k < piece, &L.ring[((uint32_t)op + k) & RMASK], v, lane);
+                ring_store(k < piece, (((uint32_t)op + k)) & RMASK, v, lane);
             }
             op += piece;
             done += piece;
@@ -1729,6 +1782,7 @@ struct Decoder {
 #if PZG_DEVICE_PASS && PZG_DMA_PREFETCH
         br.pf = L.pf;
 #endif
+        set_far_base();
         br.start(in, in_len, 0);
         PZG_T0(tall);
         if (in_len >> 34) fail(ST_TRUNCATED, 0, 0);  // the reader indexes dwords with 32 bits: 16 GiB per stream (include/pzg.h)
@@ -1839,7 +1893,7 @@ struct Decoder {
         for (uint32_t k0 = 0; k0 < use; k0 += PZG_WAVE) {
             const uint32_t k = k0 + lane;  // byte `k + 1` positions before the output start
             const uint8_t v = dict[dict_len - 1u - (k < use ? k : use - 1u)];
-            sel_store(k < use, &L.ring[(0u - 1u - k) & RMASK], v, lane);
+            ring_store(k < use, ((0u - 1u - k)) & RMASK, v, lane);
         }
         hist_extra = use;
         wave_sync();
@@ -2124,7 +2178,7 @@ struct Decoder {
             for (uint32_t k0 = 0; k0 < piece; k0 += PZG_WAVE) {
                 const uint32_t k = k0 + lane;
                 const uint8_t v = in[p + done + (k < piece ? k : piece - 1u)];
-                sel_store(k < piece, &L.ring[((uint32_t)op + k) & RMASK], v, lane);
+                ring_store(k < piece, (((uint32_t)op + k)) & RMASK, v, lane);
             }
             op += piece;
             done += piece;

@@ -193,6 +193,16 @@ PZG_FN bool lane_bit(uint64_t m, uint32_t k)
 #endif
 }
 
+// bitwise m ? a : b (ONE three-input bit operation, v_bitop3_b32 with truth table 0xca)
+PZG_FN uint32_t bit_select(uint32_t m, uint32_t a, uint32_t b)
+{
+#if PZG_DEVICE_PASS
+    return __builtin_amdgcn_bitop3_b32(m, a, b, 0xca);
+#else
+    return (a & m) | (b & ~m);
+#endif
+}
+
 // bit k of the wave-uniform mask m ? a : b, as ONE v_cndmask with the mask as its scalar operand (left to itself the
 // compiler narrows EXEC around the computation of `a` instead: two scalar instructions where the scalar unit is scarce)
 PZG_FN uint32_t mask_select(uint64_t m, uint32_t k, uint32_t a, uint32_t b)
