@@ -598,6 +598,11 @@ struct Decoder {
     // store the last segment's far bytes (see pend_m0), then flush if due: from here on every byte below `op` is in the ring
     PZG_FN void complete_pending()
     {
+        pending_stores();
+        maybe_flush();
+    }
+    PZG_FN void pending_stores()
+    {
         if ((pend_m0 | pend_m1) != 0ull) {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             {
@@ -618,7 +623,6 @@ struct Decoder {
             }
             pend_m0 = pend_m1 = 0ull;
         }
-        maybe_flush();
     }
 
     PZG_FN void maybe_flush()
@@ -1070,14 +1074,31 @@ struct Decoder {
         t.w_hi = funnel(hi, mid, r);
         t.e = lit_table<FX>()[t.w_lo & ((1u << lit_bits<FX>()) - 1u)];
     }
+    // Second-level lookup in five vector instructions and with NO lane-dependent branch (one would send the whole token
+    // loop's control flow through the compiler's structurizer: see hot_loop): every lane looks up -- where its entry is
+    // no K_SUB, at an offset that means nothing: inside the wave's LDS that is some other word, past it the hardware
+    // returns 0 -- and keeps its own entry.  (A K_SUB entry's bits 14, 15 are clear: (e >> 14) & 0x3fc is its table's
+    // byte offset in the pool.)
+    PZG_FN uint32_t spec_sub_load(const Spec &t)
+    {
+        const uint32_t off = ((t.e >> 14) & 0x3fcu) + (ubfe(t.w_lo, LIT_BITS, t.e) << 2);
+#if PZG_DEVICE_PASS
+        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.sub) + off);
+#else
+        return (int32_t)t.e >= (int32_t)ENT_SUB ? L.sub[off >> 2] : 0u;
+#endif
+    }
+    PZG_FN void spec_sub_pick(Spec &t, uint32_t e2)
+    {
+        t.e = (int32_t)t.e >= (int32_t)ENT_SUB ? e2 : t.e;  // bit 30 set, bit 31 clear: one compare
+    }
     PZG_FN void spec_sub(Spec &t)
     {
-        // four vector instructions: compare, bit field, add, shift; the lookup itself runs under the compare's mask
-        // (the entry's bits 14, 15 are clear: (e >> 14) & 0x3fc is the table's byte offset in the pool)
-        if ((int32_t)t.e >= (int32_t)ENT_SUB) {
-            const uint32_t off = ((t.e >> 14) & 0x3fcu) + (ubfe(t.w_lo, LIT_BITS, t.e) << 2);
-            t.e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.sub) + off);
-        }
+        uint32_t e2 = spec_sub_load(t);
+#if PZG_DEVICE_PASS
+        asm("" : "+v"(e2));  // (a load that only feeds a select gets a branch around it otherwise)
+#endif
+        spec_sub_pick(t, e2);
     }
     template <bool FX>
     PZG_FN void spec_dist(Spec &t)
@@ -1117,8 +1138,12 @@ struct Decoder {
         spec_bits<FX>(a, lo0, mid0, hi0, r);
         spec_bits<FX>(b, hi0, mid1, hi1, r);
         if (!FX && use_sub) {  // wave-uniform
-            spec_sub(a);
-            spec_sub(b);
+            uint32_t ea = spec_sub_load(a), eb = spec_sub_load(b);  // (both lookups in flight together)
+#if PZG_DEVICE_PASS
+            asm("" : "+v"(ea), "+v"(eb));
+#endif
+            spec_sub_pick(a, ea);
+            spec_sub_pick(b, eb);
         }
         spec_dist<FX>(a);
         spec_dist<FX>(b);
@@ -1239,27 +1264,28 @@ struct Decoder {
     // independent, so their LDS round trips overlap, and the per-window bookkeeping is paid once.
     // Precondition: br.window2_ok(); qn < QCAP.  Falls back to the first half alone when the queue
     // cannot take both.  Returns true when the token now at the cursor must go through token_step_checked().
+    // the 128 speculative decodes of a window: lane k's tokens at bit offsets k (TB0, TK0) and k + 64 (TB1, TK1)
     template <bool FX>
-    PZG_FN bool window_append2()
+    PZG_FN void window2_decode(LaneVec<uint32_t> &TB0, LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TB1, LaneVec<uint32_t> &TK1)
     {
         PZG_MARK("w2.begin");
-        LaneVec<uint32_t> TB0, TK0, TB1, TK1;
 #if PZG_DEVICE_PASS
         {
             const uint32_t li = br.rp >> 5;  // < 64: the window's dwords li .. li + 7 sit in `cur`, or in `cur` and `nxt`
             const uint32_t q = (br.rp & 31u) + lane_id();
-            const uint32_t d = li + (q >> 5), a = d << 2, r = q & 31u;
-            uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
-            uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
-            uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
-            uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
-            uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
+            const uint32_t d = li + (q >> 5), r = q & 31u;
+            // ((d + i) << 2, not (d << 2) + 4 * i: the compiler folds the constant into the instruction's offset field)
+            uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.cur);
+            uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.cur);
+            uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.cur);
+            uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 3u) << 2), (int)br.cur);
+            uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 4u) << 2), (int)br.cur);
             if (li > 56u) {  // (one window in nine) the same gathers from the next chunk for the dwords past this one
-                const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.nxt);
-                const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.nxt);
-                const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.nxt);
-                const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.nxt);
-                const uint32_t n4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.nxt);
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.nxt);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.nxt);
+                const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.nxt);
+                const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 3u) << 2), (int)br.nxt);
+                const uint32_t n4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 4u) << 2), (int)br.nxt);
                 lo0 = d >= 64u ? n0 : lo0;  // (the crossbar index wraps modulo 64, so dword d of `nxt` is lane d - 64)
                 mid0 = d + 1u >= 64u ? n1 : mid0;
                 hi0 = d + 2u >= 64u ? n2 : hi0;
@@ -1281,6 +1307,13 @@ struct Decoder {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
         prof[6] += 2;
 #endif
+    }
+
+    template <bool FX>
+    PZG_FN bool window_append2()
+    {
+        LaneVec<uint32_t> TB0, TK0, TB1, TK1;
+        window2_decode<FX>(TB0, TK0, TB1, TK1);
         // ---- the walk: first half, and unless it ended at a stopper, the second -------------------------
         // The common case is written straight through (no flags to merge): both halves walked, no stopper, the queue
         // takes every token.  Anything else goes through window2_rare().
@@ -1428,11 +1461,23 @@ struct Decoder {
             chunks += 1u;
         }
     }
-    PZG_FN int emit_segment()
+    PZG_FN int emit_segment() { return emit_body<false>(); }
+
+    // FAST (hot_loop): returns EMIT_BAIL, with nothing changed that emit_segment() would not redo, where the general
+    // code has lane-dependent branches -- a flush is due, or the queue's head is a match for copy_match().
+    static constexpr int EMIT_BAIL = -1;
+    template <bool FAST>
+    PZG_FN int emit_body()
     {
         PZG_MARK("e.begin");
         PZG_T0(t_a);
-        complete_pending();  // the previous segment's bytes must all be in the ring from here on
+        // the previous segment's bytes must all be in the ring from here on
+        if (FAST) {
+            pending_stores();
+            if ((uint32_t)(op - flushed) >= FLUSH_AT) return EMIT_BAIL;
+        } else {
+            complete_pending();
+        }
         PZG_ACCW(8, t_a);
         if (RES && op + 512u > cap) return ST_OUT_FULL;  // (resumable: never produce past this call's output room)
         PZG_MARK("e.scan");
@@ -1463,6 +1508,7 @@ struct Decoder {
         PZG_MARK("e.v");
         PZG_ACCW(9, t_b);
         if (v == 0u) {
+            if (FAST) return EMIT_BAIL;
             const uint32_t tk = lane_get(QT, 0u), dist = tk & 0xffffu, len = (tk >> 16) & 511u;
             if ((uint64_t)dist > op + (RING_BITS == 15 ? hist_extra : 0u)) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
@@ -1571,12 +1617,64 @@ struct Decoder {
         return false;
     }
 
+    // The hot loop: 128-bit windows while the queue is short of QHIGH tokens, segments while it is not, for as long as
+    // neither needs code with a lane-dependent branch.  The compiler rebuilds the control flow of every region that holds
+    // one such branch with flags and flag tests (its structurizer), including all the wave-uniform branches around it:
+    // ~35 scalar instructions per window in the token loop as a whole.  This loop holds none, has ONE exit, and the reason
+    // for leaving passes through an opaque statement (nothing can be threaded from inside the loop to the handlers), so it
+    // stays a region of plain scalar branches.  HL_WINDOW: the window decoded last (TK0, TK1, S0, S1, k0, k1) is one for
+    // window2_rare(); HL_GENERAL: the general token loop has to take a step (stream tail, flush, copy_match).
+    enum : uint32_t { HL_GENERAL = 1, HL_WINDOW = 2 };
+    template <bool FX>
+    PZG_FN uint32_t hot_loop(LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TK1, uint64_t &S0, uint64_t &S1, uint32_t &k0, uint32_t &k1)
+    {
+        uint32_t why;
+        for (;;) {
+            if (qn < QHIGH) {
+                if (!br.window2_ok()) {
+                    why = HL_GENERAL;
+                    break;
+                }
+                LaneVec<uint32_t> TB0, TB1;
+                window2_decode<FX>(TB0, TK0, TB1, TK1);
+                S0 = 0;
+                S1 = 0;
+                k1 = 0;
+                k0 = walk_half(TB0, 0u, S0);
+                why = HL_WINDOW;
+                if (k0 >= 64u) break;
+                k1 = walk_half(TB1, k0, S1);
+                if (k1 >= 64u) break;
+                const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
+                if (qn + nt0 + nt1 > QCAP) break;
+                queue_append(TK0, S0, nt0, TK1, S1, nt1);
+                br.drop_short(k1 + 128u);
+                continue;
+            }
+            if (emit_body<true>() != ST_OK) {
+                why = HL_GENERAL;
+                break;
+            }
+        }
+#if PZG_DEVICE_PASS
+        asm volatile("" : "+s"(why));
+#endif
+        return why;
+    }
+
     template <bool FX>
     PZG_FN int token_loop()
     {
         for (;;) {
             PZG_T0(tw);
-            const bool checked = qn < QHIGH && fill_queue<FX>();
+            bool checked;
+            uint32_t why = HL_GENERAL;
+            LaneVec<uint32_t> TK0, TK1;
+            uint64_t S0 = 0, S1 = 0;
+            uint32_t k0 = 0, k1 = 0;
+            if (!RES) why = hot_loop<FX>(TK0, TK1, S0, S1, k0, k1);
+            if (why == HL_WINDOW) checked = window2_rare(TK0, TK1, S0, S1, k0, k1);
+            else checked = qn < QHIGH && fill_queue<FX>();
             PZG_ACC(4, tw);
             if (!checked) {
                 PZG_T0(te);
