@@ -507,7 +507,13 @@ struct Decoder {
     // Writes produced bytes [flushed, to) and advances the Adler state over them.  `flushed` is
     // always a multiple of 16, so ring offsets and (for a 16-byte aligned output) global
     // addresses are 16-byte aligned: one ds_read_b128 + one global_store_dwordx4 per lane.
-    PZG_FN void flush_to(uint64_t to)
+    PZG_FN void flush_to(uint64_t to) { flush_span<false>(to); }
+    PZG_FN bool out_aligned() const { return (((uintptr_t)out) & 15u) == 0u; }
+    // FULL (hot_loop): the span is a whole number of 64-vector rounds (a multiple of 1 KiB), the output is 16-byte aligned
+    // and the span ends inside the capacity -- every lane has a whole vector to move in every round, no lane-dependent
+    // branch is left.
+    template <bool FULL>
+    PZG_FN void flush_span(uint64_t to)
     {
         PZG_T0(tf);
         wave_sync();
@@ -516,7 +522,7 @@ struct Decoder {
         const uint32_t n = (uint32_t)(to - from);
         const uint32_t nvec = (n + 15u) >> 4;
         const uint32_t lane = lane_id();
-        const bool out_al = (((uintptr_t)out) & 15u) == 0u;
+        const bool out_al = FULL || out_aligned();
 #if PZG_DEVICE_PASS
         uint32_t a_l = 0, w_l = 0, u_l = 0;  // a lane sees at most RING / 1024 vectors per flush: no overflow
 #else
@@ -525,7 +531,7 @@ struct Decoder {
 #pragma nounroll
         for (uint32_t it = 0; it * PZG_WAVE < nvec; ++it) {
             const uint32_t j = it * PZG_WAVE + lane;
-            if (j < nvec) {
+            if (FULL || j < nvec) {
                 const uint64_t pos = from + (uint64_t)j * 16u;
                 const uint32_t roff = (uint32_t)pos & RMASK;
 #if PZG_DEVICE_PASS
@@ -536,7 +542,7 @@ struct Decoder {
                 const uint32_t *rp = (const uint32_t *)(const void *)&L.ring[roff];
                 uint32_t x0 = rp[0], x1 = rp[1], x2 = rp[2], x3 = rp[3];
 #endif
-                const uint32_t valid = (to - pos) >= 16u ? 16u : (uint32_t)(to - pos);
+                const uint32_t valid = FULL ? 16u : (to - pos) >= 16u ? 16u : (uint32_t)(to - pos);
                 if (valid < 16u) {  // zero the bytes past `to`: they add nothing to either sum
                     uint32_t m0 = valid >= 4u ? ~0u : ((1u << (8u * valid)) - 1u);
                     uint32_t m1 = valid >= 8u ? ~0u : valid <= 4u ? 0u : ((1u << (8u * (valid - 4u))) - 1u);
@@ -547,7 +553,7 @@ struct Decoder {
                     x2 &= m2;
                     x3 &= m3;
                 }
-                if (out_al && valid == 16u && pos + 16u <= cap) {
+                if (FULL || (out_al && valid == 16u && pos + 16u <= cap)) {
                     uint32_t *gp = (uint32_t *)(void *)(out + pos);
 #if PZG_DEVICE_PASS
                     u32x4 v = {x0, x1, x2, x3};
@@ -1474,7 +1480,11 @@ struct Decoder {
         // the previous segment's bytes must all be in the ring from here on
         if (FAST) {
             pending_stores();
-            if ((uint32_t)(op - flushed) >= FLUSH_AT) return EMIT_BAIL;
+            if ((uint32_t)(op - flushed) >= FLUSH_AT) {  // whole KiB only (the general flush goes up to op & ~15)
+                const uint64_t to = flushed + ((uint32_t)(op - flushed) & ~1023u);
+                if (!out_aligned() || to > cap) return EMIT_BAIL;
+                flush_span<true>(to);
+            }
         } else {
             complete_pending();
         }
