@@ -508,6 +508,40 @@ struct Decoder {
     // always a multiple of 16, so ring offsets and (for a 16-byte aligned output) global
     // addresses are 16-byte aligned: one ds_read_b128 + one global_store_dwordx4 per lane.
     PZG_FN void flush_to(uint64_t to) { flush_span<false>(to); }
+    // One KiB from produced-byte p (a multiple of 16) on, whole and aligned: one vector per lane, and every sum fits 32
+    // bits -- a lane's byte sum s <= 16 * 255, its weighted sum (1008 - 16 lane) s + sum (16 - i) d_i < 2^23, the wave's
+    // < 2^29 -- so nothing is reduced modulo 65521 before the two scalar updates.
+    PZG_FN void flush_kib(uint64_t p)
+    {
+        const uint32_t lane = lane_id();
+        uint32_t a_l = 0, b_l = 0;
+#pragma nounroll
+        for (uint32_t it = 0; it * PZG_WAVE < 64u; ++it) {  // (one round on the device; the one-lane host model takes 64)
+            const uint32_t j = it * PZG_WAVE + lane;
+            const uint64_t pos = p + (uint64_t)j * 16u;
+            const uint32_t roff = (uint32_t)pos & RMASK;
+            uint32_t *gp = (uint32_t *)(void *)(out + pos);
+#if PZG_DEVICE_PASS
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 rv = *(const u32x4 *)(const void *)&L.ring[roff];  // ds_read_b128
+            *(u32x4 *)gp = rv;
+            const uint32_t x0 = rv.x, x1 = rv.y, x2 = rv.z, x3 = rv.w;
+#else
+            const uint32_t *rp = (const uint32_t *)(const void *)&L.ring[roff];
+            const uint32_t x0 = rp[0], x1 = rp[1], x2 = rp[2], x3 = rp[3];
+            gp[0] = x0; gp[1] = x1; gp[2] = x2; gp[3] = x3;
+#endif
+            // Adler32.hs:29-34 advanceNoMod over 16 bytes at once: s = sum d_i, t = sum (16-i) d_i
+            const uint32_t s = sum4(x0, sum4(x1, sum4(x2, sum4(x3, 0u))));
+            const uint32_t t = dot4(x0, 0x0D0E0F10u, dot4(x1, 0x090A0B0Cu, dot4(x2, 0x05060708u, dot4(x3, 0x01020304u, 0u))));
+            a_l += s;
+            b_l += (1008u - 16u * j) * s + t;  // weight of byte i of vector j: 1024 - 16 j - i
+        }
+        const uint32_t sum_a = wave_sum(a_l), sum_b = wave_sum(b_l);
+        // Adler32.hs:22-27 in block form: A' = A + sum d ; B' = B + n*A + sum (n - pos) d
+        adler_b = (adler_b + 1024u * adler_a + sum_b) % ADLER_MOD;
+        adler_a = (adler_a + sum_a) % ADLER_MOD;
+    }
     PZG_FN bool out_aligned() const { return (((uintptr_t)out) & 15u) == 0u; }
     // FULL (hot_loop): the span is a whole number of 64-vector rounds (a multiple of 1 KiB), the output is 16-byte aligned
     // and the span ends inside the capacity -- every lane has a whole vector to move in every round, no lane-dependent
@@ -519,6 +553,14 @@ struct Decoder {
         wave_sync();
         const uint64_t from = flushed;
         if (to <= from) return;
+        if (FULL) {
+            for (uint64_t p = from; p < to; p += 1024u) flush_kib(p);
+            flushed = to;
+            set_far_base();
+            wave_sync();
+            PZG_ACC(3, tf);
+            return;
+        }
         const uint32_t n = (uint32_t)(to - from);
         const uint32_t nvec = (n + 15u) >> 4;
         const uint32_t lane = lane_id();
@@ -1194,16 +1236,18 @@ struct Decoder {
     {
         LaneVec<uint32_t> DEST, R0, R1;
         PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = mask_select(tokens0, k, qn + mbcnt_k(tokens0, k), 63u);
+            PZG_LV(DEST, k) = mask_select(tokens0, k, mbcnt_slot4_k(tokens0, qn << 2, k), 63u << 2);
         PZG_LANES_END
-        lanes_scatter(R0, TK0, DEST);
+        lanes_scatter4(R0, TK0, DEST);
         PZG_LANES_BEGIN(k)
-            PZG_LV(DEST, k) = mask_select(tokens1, k, qn + nt0 + mbcnt_k(tokens1, k), 63u);
+            PZG_LV(DEST, k) = mask_select(tokens1, k, mbcnt_slot4_k(tokens1, (qn + nt0) << 2, k), 63u << 2);
         PZG_LANES_END
-        lanes_scatter(R1, TK1, DEST);
+        lanes_scatter4(R1, TK1, DEST);
+        // queue slots qn .. qn + nt0 - 1 take the first half's tokens, the next nt1 the second's (two scalar bit-field masks,
+        // two selects; qn + nt0 + nt1 <= QCAP = 63)
+        const uint64_t slots0 = bit_field_mask(nt0, qn), slots1 = bit_field_mask(nt1, qn + nt0);
         PZG_LANES_BEGIN(j)
-            const uint32_t rel = j - qn;  // (wraps for j < qn)
-            PZG_LV(QT, j) = rel < nt0 ? PZG_LV(R0, j) : rel < nt0 + nt1 ? PZG_LV(R1, j) : PZG_LV(QT, j);
+            PZG_LV(QT, j) = mask_select(slots1, j, PZG_LV(R1, j), mask_select(slots0, j, PZG_LV(R0, j), PZG_LV(QT, j)));
         PZG_LANES_END
         qn += nt0 + nt1;
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS

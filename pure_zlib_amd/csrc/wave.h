@@ -98,17 +98,27 @@ PZG_FN void wave_sync()
 #endif
 }
 
+#if PZG_DEVICE_PASS
+// DPP controls (gfx9/CDNA): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+#endif
+
 // sum over the wave, result uniform
 PZG_FN uint32_t wave_sum(uint32_t x)
 {
 #if PZG_DEVICE_PASS
-    x += (uint32_t)__shfl_xor((int)x, 32);
-    x += (uint32_t)__shfl_xor((int)x, 16);
-    x += (uint32_t)__shfl_xor((int)x, 8);
-    x += (uint32_t)__shfl_xor((int)x, 4);
-    x += (uint32_t)__shfl_xor((int)x, 2);
-    x += (uint32_t)__shfl_xor((int)x, 1);
-    return uni(x);
+    // the inclusive scan's six DPP additions, the total read from lane 63 (a crossbar butterfly costs six instructions a step)
+    x += dpp_zero<0x111, 0xf>(x);
+    x += dpp_zero<0x112, 0xf>(x);
+    x += dpp_zero<0x114, 0xf>(x);
+    x += dpp_zero<0x118, 0xf>(x);
+    x += dpp_zero<0x142, 0xa>(x);
+    x += dpp_zero<0x143, 0xc>(x);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 #else
     return x;
 #endif
@@ -228,6 +238,30 @@ PZG_FN uint32_t mbcnt_k(uint64_t m, uint32_t k)
 #endif
 }
 
+// 4 * (base + number of set bits of m below lane k), base4 = 4 * base: a lane index as the crossbar instructions address
+// it (the shift and the addition are one v_lshl_add_u32)
+PZG_FN uint32_t mbcnt_slot4_k(uint64_t m, uint32_t base4, uint32_t k)
+{
+#if PZG_DEVICE_PASS
+    (void)k;
+    return (mbcnt(m) << 2) + base4;
+#else
+    return base4 + 4u * (uint32_t)__builtin_popcountll(m & ((1ull << k) - 1ull));
+#endif
+}
+
+// `width` ones from bit `off` on (ONE s_bfm_b64; width < 64, off < 64)
+PZG_FN uint64_t bit_field_mask(uint32_t width, uint32_t off)
+{
+#if PZG_DEVICE_PASS
+    uint64_t m;
+    asm("s_bfm_b64 %0, %1, %2" : "=s"(m) : "s"(width), "s"(off));
+    return m;
+#else
+    return ((1ull << width) - 1ull) << off;
+#endif
+}
+
 // (hi:lo) >> r, r in [0,32): v_alignbit_b32
 // the same on wave-uniform operands: stays a scalar 64-bit shift
 PZG_FN uint32_t funnel_uniform(uint32_t hi, uint32_t lo, uint32_t r)
@@ -267,14 +301,6 @@ PZG_FN uint32_t hi_halves(uint32_t a, uint32_t b)
 }
 
 // ---- cross-lane operations on whole LaneVecs (64 lanes) ----------------------------------------
-#if PZG_DEVICE_PASS
-// DPP controls (gfx9/CDNA): row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_zero(uint32_t x)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
-}
-#endif
 
 // inclusive prefix sum across the 64 lanes
 PZG_FN void lanes_iscan_add(LaneVec<uint32_t> &x)
@@ -332,6 +358,19 @@ PZG_FN void lanes_scatter(LaneVec<uint32_t> &out, const LaneVec<uint32_t> &src, 
     LaneVec<uint32_t> tmp;
     for (uint32_t k = 0; k < 64u; ++k) tmp.v[k] = 0u;
     for (uint32_t k = 0; k < 64u; ++k) tmp.v[dst.v[k] & 63u] = src.v[k];
+    out = tmp;
+#endif
+}
+
+// the same with the destinations given as 4 * lane (the crossbar's own addressing)
+PZG_FN void lanes_scatter4(LaneVec<uint32_t> &out, const LaneVec<uint32_t> &src, const LaneVec<uint32_t> &dst4)
+{
+#if PZG_DEVICE_PASS
+    out.v = (uint32_t)__builtin_amdgcn_ds_permute((int)dst4.v, (int)src.v);
+#else
+    LaneVec<uint32_t> tmp;
+    for (uint32_t k = 0; k < 64u; ++k) tmp.v[k] = 0u;
+    for (uint32_t k = 0; k < 64u; ++k) tmp.v[(dst4.v[k] >> 2) & 63u] = src.v[k];
     out = tmp;
 #endif
 }
