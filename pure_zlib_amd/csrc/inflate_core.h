@@ -48,6 +48,12 @@
 #define PZG_MARK(name)
 #endif
 
+#ifndef PZG_WALK_UNROLL
+#define PZG_WALK_UNROLL 8
+#endif
+#define PZG_STR2(x) #x
+#define PZG_STR(x) PZG_STR2(x)
+
 namespace pzg {
 
 // ---- per-stream status codes: numerically identical to include/pzg.h -----------------------
@@ -399,7 +405,7 @@ struct BitReader {
     PZG_FN void drop_short(uint32_t n)
     {
         rp += n;
-        if (rp >= 2048u) step_chunk();
+        if (__builtin_expect(rp >= 2048u, 0)) step_chunk();
     }
     PZG_FN void align_to_byte() { drop((8u - (rp & 7u)) & 7u); }  // (32 * chunk0 is a multiple of 8)
 };
@@ -1211,11 +1217,16 @@ struct Decoder {
     {
 #if PZG_DEVICE_PASS
         uint32_t kb = k - 64u, t;
+        // (unrolled: a half holds six tokens on average, and a branch that falls through costs the wave no refetch)
         asm("1:\n\t"
+            ".rept " PZG_STR(PZG_WALK_UNROLL) "\n\t"
             "s_bitset1_b64 %0, %1\n\t"
             "v_readlane_b32 %2, %3, %1\n\t"
             "s_add_u32 %1, %1, %2\n\t"
-            "s_cbranch_scc0 1b"
+            "s_cbranch_scc1 2f\n\t"
+            ".endr\n\t"
+            "s_branch 1b\n"
+            "2:"
             : "+s"(S), "+s"(kb), "=&s"(t)
             : "v"(TB.v)
             : "scc");
@@ -1330,7 +1341,7 @@ struct Decoder {
             uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.cur);
             uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 3u) << 2), (int)br.cur);
             uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 4u) << 2), (int)br.cur);
-            if (li > 56u) {  // (one window in nine) the same gathers from the next chunk for the dwords past this one
+            if (__builtin_expect(li > 56u, 0)) {  // (one window in nine) the same gathers from the next chunk for the dwords past this one
                 const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.nxt);
                 const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.nxt);
                 const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.nxt);
@@ -1524,7 +1535,7 @@ struct Decoder {
         // the previous segment's bytes must all be in the ring from here on
         if (FAST) {
             pending_stores();
-            if ((uint32_t)(op - flushed) >= FLUSH_AT) {  // whole KiB only (the general flush goes up to op & ~15)
+            if (__builtin_expect((uint32_t)(op - flushed) >= FLUSH_AT, 0)) {  // whole KiB only (the general flush goes up to op & ~15)
                 const uint64_t to = flushed + ((uint32_t)(op - flushed) & ~1023u);
                 if (!out_aligned() || to > cap) return EMIT_BAIL;
                 flush_span<true>(to);
@@ -1561,7 +1572,7 @@ struct Decoder {
         uint32_t v = stopmask ? ctz64(stopmask) : qn;  // tokens of this segment
         PZG_MARK("e.v");
         PZG_ACCW(9, t_b);
-        if (v == 0u) {
+        if (__builtin_expect(v == 0u, 0)) {
             if (FAST) return EMIT_BAIL;
             const uint32_t tk = lane_get(QT, 0u), dist = tk & 0xffffu, len = (tk >> 16) & 511u;
             if ((uint64_t)dist > op + (RING_BITS == 15 ? hist_extra : 0u)) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
@@ -1685,7 +1696,7 @@ struct Decoder {
         uint32_t why;
         for (;;) {
             if (qn < QHIGH) {
-                if (!br.window2_ok()) {
+                if (__builtin_expect(!br.window2_ok(), 0)) {
                     why = HL_GENERAL;
                     break;
                 }
@@ -1696,11 +1707,11 @@ struct Decoder {
                 k1 = 0;
                 k0 = walk_half(TB0, 0u, S0);
                 why = HL_WINDOW;
-                if (k0 >= 64u) break;
+                if (__builtin_expect(k0 >= 64u, 0)) break;
                 k1 = walk_half(TB1, k0, S1);
-                if (k1 >= 64u) break;
+                if (__builtin_expect(k1 >= 64u, 0)) break;
                 const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
-                if (qn + nt0 + nt1 > QCAP) break;
+                if (__builtin_expect(qn + nt0 + nt1 > QCAP, 0)) break;
                 queue_append(TK0, S0, nt0, TK1, S1, nt1);
                 br.drop_short(k1 + 128u);
                 continue;
