@@ -51,6 +51,9 @@
 #ifndef PZG_WALK_UNROLL
 #define PZG_WALK_UNROLL 8
 #endif
+#ifndef PZG_WALK_EXIT_ALIGN
+#define PZG_WALK_EXIT_ALIGN 2
+#endif
 #define PZG_STR2(x) #x
 #define PZG_STR(x) PZG_STR2(x)
 
@@ -1216,7 +1219,7 @@ struct Decoder {
     PZG_FN uint32_t walk_half(const LaneVec<uint32_t> &TB, uint32_t k, uint64_t &S)
     {
 #if PZG_DEVICE_PASS
-        uint32_t kb = k - 64u, t;
+        uint32_t kb = k | 0xffffffc0u, t;  // k - 64 for k < 64
         // (unrolled: a half holds six tokens on average, and a branch that falls through costs the wave no refetch)
         asm("1:\n\t"
             ".rept " PZG_STR(PZG_WALK_UNROLL) "\n\t"
@@ -1225,7 +1228,8 @@ struct Decoder {
             "s_add_u32 %1, %1, %2\n\t"
             "s_cbranch_scc1 2f\n\t"
             ".endr\n\t"
-            "s_branch 1b\n"
+            "s_branch 1b\n\t"
+            ".p2align " PZG_STR(PZG_WALK_EXIT_ALIGN) "\n"   // (experiment knob: padding here is never executed; measured neutral)
             "2:"
             : "+s"(S), "+s"(kb), "=&s"(t)
             : "v"(TB.v)
@@ -1258,9 +1262,9 @@ struct Decoder {
         // two selects; qn + nt0 + nt1 <= QCAP = 63)
         const uint64_t slots0 = bit_field_mask(nt0, qn), slots1 = bit_field_mask(nt1, qn + nt0);
         PZG_LANES_BEGIN(j)
-            PZG_LV(QT, j) = mask_select(slots1, j, PZG_LV(R1, j), mask_select(slots0, j, PZG_LV(R0, j), PZG_LV(QT, j)));
+            PZG_LV(QT, j) = mask_select2(slots0, slots1, j, PZG_LV(R0, j), PZG_LV(R1, j), PZG_LV(QT, j));
         PZG_LANES_END
-        qn += nt0 + nt1;
+        qn = (qn + nt0) + nt1;  // (associated as the callers' capacity tests are: one addition for both)
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
         prof[7] += nt0 + nt1;
 #endif
@@ -1332,15 +1336,16 @@ struct Decoder {
         PZG_MARK("w2.begin");
 #if PZG_DEVICE_PASS
         {
-            const uint32_t li = br.rp >> 5;  // < 64: the window's dwords li .. li + 7 sit in `cur`, or in `cur` and `nxt`
-            const uint32_t q = (br.rp & 31u) + lane_id();
-            const uint32_t d = li + (q >> 5), r = q & 31u;
-            // ((d + i) << 2, not (d << 2) + 4 * i: the compiler folds the constant into the instruction's offset field)
-            uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.cur);
-            uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.cur);
-            uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.cur);
-            uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 3u) << 2), (int)br.cur);
-            uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 4u) << 2), (int)br.cur);
+            // lane k's first token starts at bit p = rp + k of the chunk: dword d = p >> 5 (the window's dwords sit in `cur`,
+            // or in `cur` and `nxt`), bit r = p & 31 of it.  The crossbar takes a byte address and ignores its low two bits
+            // (lane = address[7:2]) and the funnel shift its amount's high bits, so p >> 3 and p themselves will do.
+            const uint32_t li = br.rp >> 5;
+            const uint32_t r = br.rp + lane_id(), a = r >> 3, d = r >> 5;
+            uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
+            uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
+            uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
+            uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
+            uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
             if (__builtin_expect(li > 56u, 0)) {  // (one window in nine) the same gathers from the next chunk for the dwords past this one
                 const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.nxt);
                 const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.nxt);
@@ -1702,6 +1707,18 @@ struct Decoder {
                 }
                 LaneVec<uint32_t> TB0, TB1;
                 window2_decode<FX>(TB0, TK0, TB1, TK1);
+#if PZG_DEVICE_PASS && defined(PZG_EXP_NOP)   // cost-model experiments (never in the product build): per window,
+                asm volatile(".rept " PZG_STR(PZG_EXP_NOP) "\n\ts_nop 0\n\t.endr");                 // 4-byte no-ops
+#endif
+#if PZG_DEVICE_PASS && defined(PZG_EXP_VALU4)
+                { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU4) "\n\tv_mov_b32_e32 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 4-byte vector
+#endif
+#if PZG_DEVICE_PASS && defined(PZG_EXP_VALU8)
+                { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU8) "\n\tv_mov_b32_e64 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 8-byte vector
+#endif
+#if PZG_DEVICE_PASS && defined(PZG_EXP_SALU4)
+                { uint32_t x = qn; asm volatile(".rept " PZG_STR(PZG_EXP_SALU4) "\n\ts_mov_b32 %0, %0\n\t.endr" : "+s"(x)); qn = x; }  // 4-byte scalar
+#endif
                 S0 = 0;
                 S1 = 0;
                 k1 = 0;
@@ -1711,7 +1728,7 @@ struct Decoder {
                 k1 = walk_half(TB1, k0, S1);
                 if (__builtin_expect(k1 >= 64u, 0)) break;
                 const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
-                if (__builtin_expect(qn + nt0 + nt1 > QCAP, 0)) break;
+                if (__builtin_expect((qn + nt0) + nt1 > QCAP, 0)) break;
                 queue_append(TK0, S0, nt0, TK1, S1, nt1);
                 br.drop_short(k1 + 128u);
                 continue;

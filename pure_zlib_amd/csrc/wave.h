@@ -227,6 +227,20 @@ PZG_FN uint32_t mask_select(uint64_t m, uint32_t k, uint32_t a, uint32_t b)
 #endif
 }
 
+// m1 ? a1 : m0 ? a0 : b -- two selects in ONE statement, so that both a0 and a1 (crossbar results, typically) are asked
+// for before either is waited for
+PZG_FN uint32_t mask_select2(uint64_t m0, uint64_t m1, uint32_t k, uint32_t a0, uint32_t a1, uint32_t b)
+{
+#if PZG_DEVICE_PASS
+    (void)k;
+    uint32_t r = b;
+    asm("v_cndmask_b32_e64 %0, %0, %1, %3\n\tv_cndmask_b32_e64 %0, %0, %2, %4" : "+v"(r) : "v"(a0), "v"(a1), "s"(m0), "s"(m1));
+    return r;
+#else
+    return ((m1 >> k) & 1ull) ? a1 : ((m0 >> k) & 1ull) ? a0 : b;
+#endif
+}
+
 // number of set bits of m below lane k
 PZG_FN uint32_t mbcnt_k(uint64_t m, uint32_t k)
 {
