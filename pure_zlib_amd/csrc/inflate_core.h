@@ -1330,7 +1330,11 @@ struct Decoder {
     // Precondition: br.window2_ok(); qn < QCAP.  Falls back to the first half alone when the queue
     // cannot take both.  Returns true when the token now at the cursor must go through token_step_checked().
     // the 128 speculative decodes of a window: lane k's tokens at bit offsets k (TB0, TK0) and k + 64 (TB1, TK1)
-    template <bool FX>
+    // TAIL: the window may reach past the end of the stream.  A token that starts inside the stream and ends inside it was
+    // decoded from stream bits alone (a prefix code is settled by its own bits, whatever follows them); any other is made
+    // a stopper, so the walk ends in front of it and token_step_checked() finds what the reference finds there
+    // (the end-of-block code as a rule; a truncated stream otherwise).
+    template <bool FX, bool TAIL = false>
     PZG_FN void window2_decode(LaneVec<uint32_t> &TB0, LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TB1, LaneVec<uint32_t> &TK1)
     {
         PZG_MARK("w2.begin");
@@ -1373,13 +1377,21 @@ struct Decoder {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
         prof[6] += 2;
 #endif
+        if (TAIL) {
+            const int64_t av = br.avail();
+            const uint32_t left = av < 0 ? 0u : av > 1024 ? 1024u : (uint32_t)av;  // stream bits from the cursor on
+            PZG_LANES_BEGIN(k)
+                PZG_LV(TB0, k) |= k + PZG_LV(TB0, k) > left ? ENT_STOP : 0u;
+                PZG_LV(TB1, k) |= 64u + k + PZG_LV(TB1, k) > left ? ENT_STOP : 0u;
+            PZG_LANES_END
+        }
     }
 
-    template <bool FX>
+    template <bool FX, bool TAIL = false>
     PZG_FN bool window_append2()
     {
         LaneVec<uint32_t> TB0, TK0, TB1, TK1;
-        window2_decode<FX>(TB0, TK0, TB1, TK1);
+        window2_decode<FX, TAIL>(TB0, TK0, TB1, TK1);
         // ---- the walk: first half, and unless it ended at a stopper, the second -------------------------
         // The common case is written straight through (no flags to merge): both halves walked, no stopper, the queue
         // takes every token.  Anything else goes through window2_rare().
@@ -1681,8 +1693,14 @@ struct Decoder {
             if (qn >= QHIGH) return false;
         }
         // the last 320 bits of the stream
-        do {
-            if (!br.window_ok() || window_append<FX>()) return true;
+        if (RES) {  // (the resumable instance stops short of the end of its input: more may follow)
+            do {
+                if (!br.window_ok() || window_append<FX>()) return true;
+            } while (qn < QHIGH);
+            return false;
+        }
+        do {  // windows that may reach past the end: they stop in front of the first token that does
+            if (window_append2<FX, true>()) return true;
         } while (qn < QHIGH);
         return false;
     }
