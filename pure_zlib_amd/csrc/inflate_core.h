@@ -1021,6 +1021,9 @@ struct Decoder {
 
     PZG_FN void queue_push(uint32_t tk)  // qn < QCAP
     {
+#if !PZG_DEVICE_PASS
+        if (qn >= QCAP) __builtin_trap();  // (host model: the queue never holds more than QCAP tokens -- emit_segment's masks rely on it)
+#endif
         PZG_LANES_BEGIN(j)
             PZG_LV(QT, j) = j == qn ? tk : PZG_LV(QT, j);
         PZG_LANES_END
@@ -1312,7 +1315,7 @@ struct Decoder {
             consumed = 63u - clz64(S);
             tokens = S & ~(1ull << consumed);
         }
-        const uint32_t room = QCAP - qn;
+        const uint32_t room = QCAP - 1u - qn;  // (one slot stays free: the token after a stopper is pushed by token_step_checked())
         uint32_t nt = popc64(tokens);
         if (nt > room) {  // (a window of very short codes) take what fits, the rest is decoded again
             consumed = first_beyond(tokens, room);
@@ -1433,7 +1436,7 @@ struct Decoder {
             consumed = p + 64u;
             stopper = true;
         }
-        const uint32_t room = QCAP - qn;
+        const uint32_t room = QCAP - 1u - qn;  // (one slot stays free: the token after a stopper is pushed by token_step_checked())
         uint32_t nt0 = popc64(tokens0), nt1 = popc64(tokens1);
         if (nt0 + nt1 > room) {  // not both halves: the first alone, the second is decoded again
             if (tokens1 != 0ull || !stopper) {  // (otherwise consumed / stopper already describe the first half alone)

@@ -49,6 +49,21 @@ def test_config3_65536_fixed_huffman_4k_blobs(gpu_ctx, oracle):
     gpu_ctx.set_ring_bits(11)
 
 
+def test_262144_small_level6_blobs_2k(gpu_ctx, oracle):
+    """4,096 distinct 2 KiB level-6 blobs, 64 replicas each, in one launch (the profile sweeps' 1 M x 2 KiB batch at a
+    quarter of its size).  Small dynamic-Huffman streams end their windows at a stopper with the token queue nearly
+    full far more often than long ones: round 2 found the queue one token over its capacity here (blob 738)."""
+    texts = [corpus.zipf_text(2048, seed) for seed in range(4096)]
+    zs = [zlib.compress(t, 6) for t in texts]
+    pick = np.random.default_rng(1).integers(0, len(zs), size=262144)
+    b = DeviceBatch(texts, zs, pick)
+    for ring in (11, 12):
+        res = b.run(gpu_ctx, ring)
+        b.check_all(*res)
+    b.check_sample_vs_oracle(oracle, 128)
+    gpu_ctx.set_ring_bits(11)
+
+
 def test_config5_per_gpu_share_131072_mixed_blobs(gpu_ctx, oracle):
     """BASELINE config 5's per-GPU share: 1 M mixed 1-64 KiB level-6 blobs over 8 GPUs = 131,072 per GPU
     (4 GiB decoded per launch), laid out longest first as the sharder hands a shard over."""

@@ -270,3 +270,16 @@ def test_model_gzip_multi_member(model, oracle):
             assert ro.status == rm.status, (seed, c, ro.status, rm.status, ro.message)
             if ro.status in (10, 19):
                 assert (ro.detail0, ro.detail1) == (rm.detail0, rm.detail1)
+
+
+@pytest.mark.parametrize("rb", [15, 11])
+def test_model_queue_never_overfills(model, rb):
+    """Small level-6 blobs: a window that ends at a stopper may leave the token queue one short of full, and the token
+    after the stopper is then pushed by the checked path -- the queue must still hold at most QCAP tokens (round 2: the
+    segment's stop mask is built from `(1 << qn) - 1`; blob 738 of the 2 KiB pool decoded wrong in 1 launch of 5).
+    The host model traps in queue_push() if the invariant breaks."""
+    for seed in list(range(700, 780)) + list(range(0, 4096, 37)):
+        d = corpus.zipf_text(2048, seed)
+        z = zlib.compress(d, 6)
+        r, out = model(z, len(d), rb)
+        assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), seed
