@@ -162,7 +162,16 @@ hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream)
 // lane l runs slice l through four byte-indexed tables in LDS (slicing-by-4), starting from 0xffffffff
 // in the lane that holds the first real byte and from 0 in the others; the 64 registers are then folded
 // pairwise, R_left * x^(8 * slice * 2^level) + R_right over GF(2) modulo the CRC polynomial.
-__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)  // reflected bit order, poly 0xedb88320
+__host__ __device__ constexpr uint32_t gf2_mulmod_c(uint32_t a, uint32_t b)  // reflected bit order, poly 0xedb88320
+{
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        p ^= b & (0u - ((a >> (31 - i)) & 1u));
+        b = (b >> 1) ^ (0xedb88320u & (0u - (b & 1u)));
+    }
+    return p;
+}
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)
 {
     uint32_t p = 0;
 #pragma nounroll
@@ -171,6 +180,36 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b)  // refle
         b = (b >> 1) ^ (0xedb88320u & (0u - (b & 1u)));
     }
     return p;
+}
+// x^(8 * 2^j) mod P for j = 0 .. 47: the factor that moves a CRC register over 2^j zero bytes.  Constants, so the
+// power for any span is a product over the set bits of its length -- no squarings at run time (a power of two: one
+// table entry, no multiplication at all).
+struct CrcPowers {
+    uint32_t c[48];
+    constexpr CrcPowers() : c{}
+    {
+        uint32_t x = 0x00800000u;  // x^8 (bit 31 is x^0)
+        for (int j = 0; j < 48; ++j) {
+            c[j] = x;
+            x = gf2_mulmod_c(x, x);
+        }
+    }
+};
+__constant__ const CrcPowers crc_powers{};
+// x^(8 * n * 2^shift) mod P, n and shift wave-uniform (n * 2^shift < 2^48)
+__device__ __forceinline__ uint32_t crc_zero_bytes_factor(uint64_t n, uint32_t shift)
+{
+    uint32_t pw = 0x80000000u;  // x^0
+    bool first = true;
+#pragma nounroll
+    for (uint32_t j = 0; n != 0; ++j, n >>= 1) {
+        if (n & 1u) {
+            const uint32_t c = crc_powers.c[j + shift];
+            pw = first ? c : gf2_mulmod(pw, c);
+            first = false;
+        }
+    }
+    return pw;
 }
 
 __global__ __launch_bounds__(64) void crc32_verify_kernel(InflateArgs a)
@@ -224,19 +263,13 @@ __global__ __launch_bounds__(64) void crc32_verify_kernel(InflateArgs a)
                 step4(w);
             }
         }
-        // x^(8 * slice) mod P by square-and-multiply (wave-uniform), then the pairwise fold
-        uint32_t pw = 0x80000000u, sq = 0x40000000u;  // x^0, x^1
-#pragma nounroll
-        for (uint64_t e = 8u * slice; e != 0; e >>= 1) {
-            if (e & 1u) pw = gf2_mulmod(pw, sq);
-            sq = gf2_mulmod(sq, sq);
-        }
+        // the pairwise fold: level d moves the left register over slice * 2^d bytes (factors from the constant table)
 #pragma nounroll
         for (uint32_t d = 0; d < 6u; ++d) {
+            const uint32_t pw = crc_zero_bytes_factor(slice, d);
             const uint32_t shifted = gf2_mulmod(reg, pw);
             const uint32_t from_left = (uint32_t)__shfl_up((int)shifted, 1u << d, 64);
             if ((lane & ((2u << d) - 1u)) == (2u << d) - 1u) reg ^= from_left;
-            pw = gf2_mulmod(pw, pw);
         }
         if (lane == 63u) {
             const uint32_t ours = len ? ~reg : 0u, theirs = a.gz_expect[2 * (size_t)i];
