@@ -4,7 +4,8 @@
 //   Zlib.hs:53-69      inflateWithHeaders   -> Decoder::decode() prologue
 //   Deflate.hs:39-63   inflate/checkChecksum-> Decoder::decode() block loop + trailer
 //   Deflate.hs:65-104  inflateBlock         -> stored_block() / dynamic_header() / load_fixed_tables()
-//   Deflate.hs:106-120 runInflate           -> token_loop(): window_append2() -> token queue -> emit_segment(); token_step_checked()
+//   Deflate.hs:106-120 runInflate           -> token_loop(): hot_loop() [window2_decode() + walk_half() -> token queue ->
+//                                             emit_body<FAST>()], the general window_append2() / emit_segment(), token_step_checked()
 //   Deflate.hs:124-156 getCodeLengths       -> dynamic_header()
 //   Deflate.hs:160-237 length/distance arrays -> litlen_entry()/dist_entry() (closed forms)
 //   Deflate.hs:255-292 computeCodeValues    -> build_table() (canonical codes, wave-parallel)
@@ -21,8 +22,10 @@
 // length + distance with their extra bits) that would start k and k + 64 bits ahead of the cursor --
 // two LDS lookups each, for all 128 offsets at once -- and a scalar walk then follows the real chain
 // from offset 0 with v_readlane, so no LDS round trip is paid per token.  The real tokens are
-// compacted onto a per-wave token queue; emit_segment() turns the queue's head into <= 64 output
-// bytes with one ring gather and one ring store.
+// compacted onto a per-wave token queue; emit_body() turns the queue's head into <= 128 output
+// bytes in two passes of one ring gather and one ring store each.  hot_loop() runs these for as long as nothing
+// needs code with a lane-dependent branch: it is written (and the kernels are built) so that the compiler's
+// structurizer leaves its control flow alone -- see the comment there; that alone is worth 20 % of the kernel's speed.
 //
 // The same source compiles as a host program for the CPU model tests (see wave.h).
 #pragma once
@@ -458,7 +461,7 @@ struct Decoder {
     uint32_t phase, bfinal_cur, stored_left, deferred, ow, chunks;
     uint64_t susp_pos;          // stream bit position (relative to this call's input) at which the next call resumes
     uint64_t in_total_bits;     // 8 * the input bytes consumed by earlier calls
-    uint32_t qn;                // tokens waiting in QT (lanes 0..qn-1), see window_append()
+    uint32_t qn;                // tokens waiting in QT (lanes 0..qn-1, never more than QCAP), see queue_append()
     LaneVec<uint32_t> QT;
 #if defined(PZG_PROFILE)
     uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0 total, 1 header+tables, 2 token loop, 3 flush, 4 window_append, 5 checked steps, 6 windows, 7 tokens queued, 8-11 emit phases, 12 emit, 13 segments, 14 general copies, 15 checked steps
@@ -1043,7 +1046,7 @@ struct Decoder {
     template <bool FX> PZG_FN const uint32_t *dist_table() const { return FX ? L.sub : L.dist_lut; }
 
     // ---- Deflate.hs:106-120 runInflate: one token, every bit checked against the stream end ------
-    // Used near the end of the stream and for whatever window_append() does not handle itself
+    // Used for whatever a window does not handle itself
     // (end-of-block, codes longer than the primary tables, every error).  A literal or match is put
     // on the token queue like the windows' tokens.
     // Returns ST_OK (token consumed), 1000 (end of block consumed) or an error status.
@@ -1108,15 +1111,15 @@ struct Decoder {
 
     // ---- Deflate.hs:106-120 runInflate, wave-parallel ---------------------------------------------
     // Three cooperating pieces:
-    //   window_append()  lane k decodes the token that would start k bits ahead of the cursor
+    //   window2_decode() lane k decodes the tokens that would start k and k + 64 bits ahead of the cursor
     //                    (literal/length lookup, length extra bits, distance lookup at its own offset,
     //                    distance extra bits); a scalar walk visits the offsets that really are token
     //                    starts; those tokens are compacted onto the tail of the wave's token queue.
-    //   emit_segment()   takes tokens worth <= 64 output bytes from the head of the queue and produces
-    //                    their bytes with one ring gather and one ring store.
-    //   token_loop()     keeps the queue deep enough that a segment is (nearly) always a full 64 bytes.
-    //                    token_step_checked() decodes what a window cannot (long codes, the stream's last
-    //                    bits) onto the same queue; at an end of block or an error the queue is drained
+    //   emit_body()      takes tokens worth <= 128 output bytes from the head of the queue and produces
+    //                    their bytes in two passes of one ring gather and one ring store each.
+    //   hot_loop() / token_loop()  keep the queue deep enough that a segment is (nearly) always full.
+    //                    token_step_checked() decodes what a window cannot (long codes, end of block, errors)
+    //                    onto the same queue; at an end of block or an error the queue is drained
     //                    first, so errors surface in stream order, as in the reference.
 
     // One lane's speculative decode: the token whose first bit is bit r of (hi:mid:lo).
@@ -1167,7 +1170,7 @@ struct Decoder {
         t.d = dist_table<FX>()[t.w2 & ((1u << dist_bits<FX>()) - 1u)];
     }
     // tb = the token's length in bits, >= 128 if it is not a plain literal/match (the walk stops there); tk = the token.
-    // The entry layout (see the top of this file) makes this 14 vector instructions: a literal's entry IS its token, a
+    // The entry layout (see the top of this file) makes this 13 vector instructions: a literal's entry IS its token, a
     // match's token is the two entries' high halves side by side plus the two extra-bit fields, and tb is a byte sum.
     PZG_FN void spec_finish(const Spec &t, uint32_t &tb, uint32_t &tk)
     {
