@@ -1871,6 +1871,94 @@ struct Decoder {
     }
 
     // ---- Deflate.hs:83-101,124-156: dynamic block header ---------------------------------------------
+    // ---- code lengths, 64 bit offsets at a time (getCodeLengths, Deflate.hs:124-156, wave-parallel) -------------------
+    // Lane k decodes the code-length symbol that would start k bits ahead of the cursor; the scalar walk finds the real
+    // ones; they are ranked onto lanes 0.. in stream order, their run lengths prefix-summed into positions in `lens`, a
+    // "repeat previous" (16) takes the value of the nearest symbol before it that defines one, and every symbol's run is
+    // stored.  It stops in front of the first entry that is no symbol (dynamic_header()'s serial step reports it) and
+    // right after the symbol that completes HLIT + HDIST lengths -- exactly where the serial loop stops.
+    // Precondition: br.window_ok() (no symbol of the window reaches past the stream), n < maxl.
+    // Returns false when the entry at the cursor is one for the serial step.
+    PZG_FN bool cl_window(uint32_t &n, uint32_t &prev, uint32_t maxl)
+    {
+        const uint32_t i0 = br.chunk0 + (br.rp >> 5), boff = br.rp & 31u;
+        const uint32_t B0 = br.dword(i0), B1 = br.dword(i0 + 1u), B2 = br.dword(i0 + 2u), B3 = br.dword(i0 + 3u);
+        LaneVec<uint32_t> TB, INFO;  // INFO: run length | value << 8 | defines a value << 12 | bits << 16 | offset << 24
+        PZG_LANES_BEGIN(k)
+            const uint32_t q = boff + k, sel = q >> 5, r = q & 31u;
+            const uint32_t lo = sel == 0u ? B0 : sel == 1u ? B1 : B2, hi = sel == 0u ? B1 : sel == 1u ? B2 : B3;
+            const uint32_t w = funnel(hi, lo, r);
+            const uint32_t e = L.dist_lut[w & ((1u << CL_BITS) - 1u)];
+            const uint32_t sym = ent_val(e), cn = ent_n(e), ce = ent_cl_extra(e);
+            const uint32_t extra = (w >> cn) & ((1u << ce) - 1u);
+            const uint32_t tb = cn + ce;  // <= 7 + 7
+            const uint32_t num = sym <= 15u ? 1u : sym == 18u ? 11u + extra : 3u + extra;
+            PZG_LV(TB, k) = ent_is_stop(e) ? 128u : tb;
+            PZG_LV(INFO, k) = (num & 0xffu) | ((sym <= 15u ? sym : 0u) << 8) | ((sym != 16u ? 1u : 0u) << 12) | ((tb & 15u) << 16) | (k << 24);
+        PZG_LANES_END
+        uint64_t S = 0;
+        const uint32_t kend = walk_half(TB, 0u, S);
+        uint32_t consumed = kend + 64u;
+        if (kend >= 64u) {  // ran into an entry that is no symbol: it stays at the cursor
+            consumed = 63u - clz64(S);
+            S &= ~(1ull << consumed);
+        }
+        if (S == ~0ull) {  // (64 one-bit symbols: lane 63 is where the ranking sends what it discards)
+            S &= ~(1ull << 63);
+            consumed = 63u;
+        }
+        const uint32_t cnt = popc64(S);
+        if (cnt == 0u) return false;
+        LaneVec<uint32_t> DEST, D, INCL, DEFI;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(DEST, k) = mask_select(S, k, mbcnt_k(S, k), 63u);
+        PZG_LANES_END
+        lanes_scatter(D, INFO, DEST);
+        PZG_LANES_BEGIN(j)
+            const uint32_t d = PZG_LV(D, j);
+            PZG_LV(INCL, j) = j < cnt ? (d & 0xffu) : 0u;
+            PZG_LV(DEFI, j) = (j < cnt && ((d >> 12) & 1u) != 0u) ? j + 1u : 0u;
+        PZG_LANES_END
+        lanes_iscan_add(INCL);  // lengths written up to and including symbol j
+        lanes_iscan_max(DEFI);  // 1 + the nearest symbol at or before j that defines a value (0: none in this window)
+        LaneVec<bool> FULL;
+        PZG_LANES_BEGIN(j)
+            PZG_LV(FULL, j) = (j < cnt) & (n + PZG_LV(INCL, j) >= maxl);
+        PZG_LANES_END
+        const uint64_t full = lanes_ballot(FULL);
+        uint32_t use = cnt;
+        if (full != 0ull) {  // the serial loop reads no symbol past the one that completes maxl lengths
+            use = ctz64(full) + 1u;
+            const uint32_t dl = lane_get(D, use - 1u);
+            consumed = (dl >> 24) + ((dl >> 16) & 15u);
+        }
+        LaneVec<uint32_t> SRC, DV, VAL, NUMX;
+        PZG_LANES_BEGIN(j)
+            const uint32_t s1 = PZG_LV(DEFI, j);
+            PZG_LV(SRC, j) = s1 != 0u ? s1 - 1u : 0u;
+        PZG_LANES_END
+        lanes_gather(DV, D, SRC);
+        PZG_LANES_BEGIN(j)
+            PZG_LV(VAL, j) = PZG_LV(DEFI, j) != 0u ? ((PZG_LV(DV, j) >> 8) & 15u) : prev;
+            PZG_LV(NUMX, j) = j < use ? (PZG_LV(D, j) & 0xffu) : 0u;
+        PZG_LANES_END
+        lanes_iscan_max(NUMX);
+        const uint32_t maxnum = lane_get(NUMX, 63u);  // (wave-uniform trip count: no lane-dependent loop exit)
+#pragma nounroll
+        for (uint32_t r = 0; r < maxnum; ++r) {
+            PZG_LANES_BEGIN(j)
+                const uint32_t num = PZG_LV(D, j) & 0xffu;
+                const bool on = (j < use) & (r < num);
+                const uint32_t pos = on ? n + PZG_LV(INCL, j) - num + r : 0u;
+                sel_store(on, &L.lens[pos], (uint8_t)PZG_LV(VAL, j), j);
+            PZG_LANES_END
+        }
+        prev = lane_get(VAL, use - 1u);  // (16 leaves it as it was, 17 / 18 make it 0, a length makes it that length)
+        n += lane_get(INCL, use - 1u);
+        br.drop(consumed);
+        return true;
+    }
+
     PZG_FN int dynamic_header(uint32_t block_bit)
     {
         const uint32_t lane = lane_id();
@@ -1911,6 +1999,7 @@ struct Decoder {
         const uint32_t maxl = hlit + hdist;
         uint32_t n = 0, prev = 0;
         while (n < maxl) {
+            if (!RES && br.window_ok() && cl_window(n, prev, maxl)) continue;  // (the resumable instance stays serial: it may suspend here)
             w = br.peek32();
             const uint32_t e = uni(L.dist_lut[w & ((1u << CL_BITS) - 1u)]);
             if (int st = check_entry(e)) return st;
