@@ -35,11 +35,18 @@
 #include "wave.h"
 
 // Diagnostic build only (-DPZG_PROFILE): per-phase cycle stamps; never compiled into libpzg.so.
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS && defined(PZG_PROFILE_HDR)  // slots 8-11 = the phases of dynamic_header() instead of emit's
+#define PZG_T0(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#define PZG_ACC(slot, var) ((slot) >= 8 && (slot) <= 11 ? (void)var : (void)(prof[slot] += __builtin_amdgcn_s_memtime() - var))
+#define PZG_ACCW(slot, var) ((void)var)
+#define PZG_HACC(slot, var) prof[slot] += __builtin_amdgcn_s_memtime() - var
+#elif defined(PZG_PROFILE) && PZG_DEVICE_PASS
 #define PZG_T0(var) const uint64_t var = __builtin_amdgcn_s_memtime()
 #define PZG_ACC(slot, var) prof[slot] += __builtin_amdgcn_s_memtime() - var
 #define PZG_ACCW(slot, var) (__builtin_amdgcn_s_waitcnt(0xc07f), prof[slot] += __builtin_amdgcn_s_memtime() - var)  // after lgkmcnt(0)
+#define PZG_HACC(slot, var)
 #else
+#define PZG_HACC(slot, var)
 #define PZG_T0(var)
 #define PZG_ACC(slot, var)
 #define PZG_ACCW(slot, var)
@@ -1939,8 +1946,11 @@ struct Decoder {
         PZG_LANES_END
         lanes_gather(DV, D, SRC);
         PZG_LANES_BEGIN(j)
-            PZG_LV(VAL, j) = PZG_LV(DEFI, j) != 0u ? ((PZG_LV(DV, j) >> 8) & 15u) : prev;
-            PZG_LV(NUMX, j) = j < use ? (PZG_LV(D, j) & 0xffu) : 0u;
+            const uint32_t val = PZG_LV(DEFI, j) != 0u ? ((PZG_LV(DV, j) >> 8) & 15u) : prev;
+            PZG_LV(VAL, j) = val;
+            // `lens` is all zeros when the header starts (dynamic_header): only runs of a length that is not 0 are stored --
+            // at most 6 long (symbol 16), where a run of zeros may be 138
+            PZG_LV(NUMX, j) = (j < use && val != 0u) ? (PZG_LV(D, j) & 0xffu) : 0u;
         PZG_LANES_END
         lanes_iscan_max(NUMX);
         const uint32_t maxnum = lane_get(NUMX, 63u);  // (wave-uniform trip count: no lane-dependent loop exit)
@@ -1948,7 +1958,7 @@ struct Decoder {
         for (uint32_t r = 0; r < maxnum; ++r) {
             PZG_LANES_BEGIN(j)
                 const uint32_t num = PZG_LV(D, j) & 0xffu;
-                const bool on = (j < use) & (r < num);
+                const bool on = (j < use) & (r < num) & (PZG_LV(VAL, j) != 0u);
                 const uint32_t pos = on ? n + PZG_LV(INCL, j) - num + r : 0u;
                 sel_store(on, &L.lens[pos], (uint8_t)PZG_LV(VAL, j), j);
             PZG_LANES_END
@@ -1962,6 +1972,7 @@ struct Decoder {
     PZG_FN int dynamic_header(uint32_t block_bit)
     {
         const uint32_t lane = lane_id();
+        PZG_T0(th0);
         if (br.avail() < 14) return fail(ST_TRUNCATED, 0, 0);
         uint32_t w = br.peek32();
         const uint32_t hlit = 257u + (w & 31u);
@@ -1970,6 +1981,17 @@ struct Decoder {
         br.drop(14);
         // hclen x 3-bit lengths in codeLengthOrder (Deflate.hs:87-88,290-292)
         for (uint32_t i0 = 0; i0 < 20u; i0 += PZG_WAVE) sel_store(i0 + lane < 20u, &L.cl_lens[(i0 + lane) % 20u], 0, lane);
+        if (!RES) {  // cl_window() stores no zeros
+            constexpr uint32_t NDW = (uint32_t)(sizeof(L.lens) / 4u);
+            static_assert(sizeof(L.lens) % 4u == 0u, "lens is cleared by dwords");
+            uint32_t *lz = reinterpret_cast<uint32_t *>(L.lens);
+#pragma nounroll
+            for (uint32_t i0 = 0; i0 < NDW; i0 += PZG_WAVE) {
+                const uint32_t i = i0 + lane;
+                if (PZG_WAVE == 1u) { for (uint32_t t = 0; t < NDW; ++t) lz[t] = 0u; break; }
+                lz[i < NDW ? i : NDW - 1u] = 0u;
+            }
+        }
         wave_sync();
         if (br.avail() < (int64_t)(3u * hclen)) return fail(ST_TRUNCATED, 0, 0);
         // codeLengthOrder = 16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15 packed 5 bits each
@@ -1995,6 +2017,8 @@ struct Decoder {
         uint32_t cl_e15;
         if (!build_table<CL_BITS, TREE_CODELEN>(L.cl_lens, 19u, L.dist_lut, &L.lit_meta, &cl_e15)  /* (its meta is never read; lit_meta is rebuilt below) */)
             return fail(ST_HUFF_BUILD, TREE_CODELEN, block_bit);
+        PZG_HACC(8, th0);
+        PZG_T0(th1);
         // getCodeLengths (Deflate.hs:124-156) over HLIT+HDIST as ONE sequence
         const uint32_t maxl = hlit + hdist;
         uint32_t n = 0, prev = 0;
@@ -2033,12 +2057,17 @@ struct Decoder {
             n += num;
         }
         wave_sync();
+        PZG_HACC(9, th1);
+        PZG_T0(th2);
         // litTree first, then distTree (Deflate.hs:98-99): errors surface in that order
         if (!build_table<LIT_BITS, TREE_LITLEN>(L.lens, hlit, L.lit_lut, &L.lit_meta, &lit_e15))
             return fail(ST_HUFF_BUILD, TREE_LITLEN, block_bit);
+        PZG_HACC(10, th2);
+        PZG_T0(th3);
         dist_n = n - hlit;
         if (!build_table<DIST_BITS, TREE_DIST>(L.lens + hlit, n - hlit, L.dist_lut, &L.dist_meta, &dist_e15))
             return fail(ST_HUFF_BUILD, TREE_DIST, block_bit);
+        PZG_HACC(11, th3);
         return ST_OK;
     }
 

@@ -39,8 +39,12 @@ prof = np.zeros((nstreams, 16), np.uint64)
 L.pzg_prof_buffer(ctx.handle, nstreams, prof.ctypes.data)
 m = prof.astype(np.float64).mean(axis=0)
 print(f"streams {nstreams} x {size} B; kernel {ms:.3f} ms; status ok {int((status==0).sum())}; outputs ok {all(out_buf[int(out_off[k]):int(out_off[k])+size].tobytes()==datas[k%64] for k in range(min(nstreams,64)))}")
+if os.environ.get("PZG_PROF_HDR"):
+    hdr = ["  hdr: HCLEN + code-length table", "  hdr: code lengths", "  hdr: literal/length table", "  hdr: distance table"]
 names = ["total", "header+tables", "token loop", "flush+adler", "window_append", "checked steps", "#windows", "#tokens queued",
          "  emit: complete_pending", "  emit: scan+stop", "  complete_pending: wait for far bytes", "  emit: far", "emit_segment", "#segments", "#general copies", "#checked steps"]
+if os.environ.get("PZG_PROF_HDR"):
+    names[8:12] = hdr
 for i, nme in enumerate(names):
     if nme == "-":
         continue
