@@ -320,13 +320,15 @@ def test_cxx_module_mirror_reads_like_the_reference_tests():
 
 def test_gzip_members_extension(ctx, oracle):
     """SURVEY 8f row 4 (an extension: the reference has no gzip): RFC 1952 members through PZG_GZIP -- same DEFLATE
-    kernel, gzip header forms, CRC-32 (slicing + GF(2) fold kernel) and ISIZE verified on the device -- against
+    kernel, gzip header forms, CRC-32 (per-lane accumulators over coalesced 1 KiB blocks) and ISIZE verified on the device -- against
     system zlib (wbits 31) for valid members of many sizes and the oracle for corrupted ones."""
     import pure_zlib_amd as P
     streams, datas = [], []
-    sizes = [0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1000, 4093, 4096, 33000, 70001, 262144 + 3, 1 << 20]
+    # (the CRC kernel works in 1 KiB blocks of 64 x 16 bytes, front-padded: lengths around every boundary of both)
+    sizes = [0, 1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 1007, 1008, 1009, 1023, 1024, 1025, 2047, 2048,
+             2049, 4093, 4096, 33000, 70001, 262144 + 3, 1 << 20]
     for seed in range(300):
-        n = sizes[seed % len(sizes)] if seed % 3 == 0 else (seed * 131) % 20000
+        n = sizes[(seed // 3) % len(sizes)] if seed % 3 == 0 else (seed * 131) % 20000
         d = corpus.mixed_data(n, seed) if seed % 2 else corpus.html_slice(min(n, 100000), seed)
         streams.append(corpus.gzip_member(d, seed))
         datas.append(d)
