@@ -101,9 +101,12 @@ enum { TREE_CODELEN = 0, TREE_LITLEN = 1, TREE_DIST = 2 };
 #endif
 constexpr int LIT_BITS = PZG_LIT_BITS;  // primary literal/length LUT: 2^8 x 4 B = 1 KiB (LDS is what bounds residency)
 #ifndef PZG_SUB_ENTRIES
-#define PZG_SUB_ENTRIES 188
+#define PZG_SUB_ENTRIES 252
 #endif
-constexpr uint32_t SUB_ENTRIES = PZG_SUB_ENTRIES;   // pool of second-level entries for literal/length codes longer than LIT_BITS
+// pool of second-level entries for literal/length (then distance) codes longer than the primary tables resolve: 252 fills the
+// wave's LDS up to the 6 KiB that 26 waves per CU leave each (188 -> 252: literal-heavy data +12 %); an entry's index is 8 bits
+constexpr uint32_t SUB_ENTRIES = PZG_SUB_ENTRIES;
+static_assert(SUB_ENTRIES <= 256u, "K_SUB entries hold an 8-bit pool index");
 constexpr uint32_t SUB_BITS_MAX = 5;    // a second-level table resolves at most this many further bits
 #ifndef PZG_SUB_MIN
 #define PZG_SUB_MIN 3
