@@ -107,7 +107,10 @@ constexpr int LIT_BITS = PZG_LIT_BITS;  // primary literal/length LUT: 2^8 x 4 B
 // wave's LDS up to the 6 KiB that 26 waves per CU leave each (188 -> 252: literal-heavy data +12 %); an entry's index is 8 bits
 constexpr uint32_t SUB_ENTRIES = PZG_SUB_ENTRIES;
 static_assert(SUB_ENTRIES <= 256u, "K_SUB entries hold an 8-bit pool index");
-constexpr uint32_t SUB_BITS_MAX = 5;    // a second-level table resolves at most this many further bits
+#ifndef PZG_SUB_BITS_MAX
+#define PZG_SUB_BITS_MAX 5
+#endif
+constexpr uint32_t SUB_BITS_MAX = PZG_SUB_BITS_MAX;    // a second-level table resolves at most this many further bits
 #ifndef PZG_SUB_MIN
 #define PZG_SUB_MIN 3
 #endif
