@@ -149,7 +149,7 @@ hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream)
     if (a.n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    uint32_t waves = (uint32_t)num_cus * 4u;  // 35.8 KiB of LDS per wave: four per CU
+    uint32_t waves = (uint32_t)num_cus * 4u;  // 36 KiB of LDS per wave: four per CU
     if (waves > a.n) waves = a.n;
     hipLaunchKernelGGL(inflate_resume_kernel, dim3(waves), dim3(64), 0, stream, a);
     return hipGetLastError();
