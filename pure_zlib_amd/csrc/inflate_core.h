@@ -61,6 +61,9 @@
 #ifndef PZG_WALK_UNROLL
 #define PZG_WALK_UNROLL 8
 #endif
+#ifndef PZG_HOT_ALIGN
+#define PZG_HOT_ALIGN 6
+#endif
 #ifndef PZG_WALK_EXIT_ALIGN
 #define PZG_WALK_EXIT_ALIGN 2
 #endif
@@ -822,6 +825,35 @@ struct Decoder {
     // lens[0..n) in LDS.  Builds the 2^P primary LUT, the sorted-symbol permutation and the
     // per-length first/count/offset table.  Returns false when the code is over-subscribed,
     // which is exactly when createHuffmanTree returns Left (any overlap of canonical codes).
+    // how many bits past its P-bit prefix c_p the longest code with that prefix has (0: none / lane not on), capped at
+    // SUB_DEPTH_MAX: the codes of length l are the canonical range [first[l], first[l] + count[l]) at that length
+    static constexpr uint32_t SUB_DEPTH_MAX = 7u;
+#ifndef PZG_SUB_LONG_RATE
+#define PZG_SUB_LONG_RATE 16
+#endif
+    static constexpr uint32_t SUB_LONG_RATE = PZG_SUB_LONG_RATE;  // (units of 2^-15: 16 = one token in 2048)
+
+    // (metav: lane l holds first[l] << 16 | count[l] -- a register, so that no LDS round trip is paid per length)
+    template <int P>
+    PZG_FN uint32_t sub_depth(const TreeMeta *meta, uint32_t metav, uint32_t c_p, bool on)
+    {
+        uint32_t depth = 0;
+#pragma nounroll
+        for (uint32_t l = (uint32_t)P + 1u; l < 16u; ++l) {
+#if PZG_DEVICE_PASS
+            (void)meta;
+            const uint32_t fc = read_lane(metav, l), cnt_l = fc & 0xffffu, first_l = fc >> 16;
+#else
+            (void)metav;
+            const uint32_t cnt_l = meta->count[l], first_l = meta->first[l];
+#endif
+            const uint32_t sh = l - (uint32_t)P;
+            const bool hit = on && cnt_l != 0u && c_p >= (first_l >> sh) && c_p <= ((first_l + cnt_l - 1u) >> sh);
+            depth = hit ? (sh < SUB_DEPTH_MAX ? sh : SUB_DEPTH_MAX) : depth;
+        }
+        return depth;
+    }
+
     template <int P, int TREE>
     PZG_FN bool build_table(const uint8_t *lens, uint32_t n, uint32_t *lut, TreeMeta *meta, uint32_t *e15_out)
     {
@@ -845,12 +877,14 @@ struct Decoder {
         wave_sync();
         // next_code (step2, Deflate.hs:273-278), offsets, Kraft sum; wave-uniform, kept in LDS (meta)
         uint32_t code = 0, prev = 0, e15 = 0, covered_p = 0, maxlen = 0;
+        uint32_t metav = 0;  // lane l: first[l] << 16 | count[l] (see sub_depth)
 #pragma nounroll
         for (uint32_t l = 1; l < 16u; ++l) {
             const uint32_t c = uni(L.cnt[l]);
             if (c) maxlen = l;
             code = (code + prev) << 1;
             prev = c;
+            metav = lane == l ? ((code & 0xffffu) << 16) | c : metav;
             if (lane == 0u) {
                 meta->count[l] = (uint16_t)c;
                 meta->first[l] = (uint16_t)code;
@@ -869,7 +903,16 @@ struct Decoder {
         // when the literal/length code has enough long prefixes for it to pay (use_sub).  Whatever the
         // tables do not resolve (longer codes, holes of an incomplete code) stays K_LONG and goes the
         // exact way: decode_long().
-        uint32_t sb = 0, np_fit = 0, sub0 = 0;
+        // Two ways to share the pool.  UNIFORM: every long prefix gets 2^sb entries, sb the largest that fits (cheap to set
+        // up: the K_SUB entries are arithmetic).  When that leaves more than SUB_LONG_RATE of the tokens to decode_long() --
+        // a code of length l is used once in 2^l tokens, so the fraction is a sum over the histogram -- PER PREFIX: each
+        // prefix gets a table as deep as ITS longest code needs; the canonical order puts the longest codes behind the
+        // fewest prefixes, so the pool goes much further (literal-heavy data: 3x fewer checked steps, +33 %), at ~1,400
+        // more scalar instructions per header (text would lose 1 % to them: it keeps the uniform tables).  If the depths
+        // do not fit they are capped at the largest value that does (dcap); if two entries per prefix do not fit either,
+        // only the first np_fit prefixes get a table.
+        uint32_t np_fit = 0, sub0 = 0, dcap = 0, sub_total = 0, sb = 0;
+        bool uniform = true;
         if (TREE != TREE_CODELEN) {
             sub0 = TREE == TREE_DIST ? lit_sub_used : 0u;
             const uint32_t pool = SUB_ENTRIES - sub0;
@@ -880,18 +923,58 @@ struct Decoder {
                 sb = maxlen - (uint32_t)P < SUB_BITS_MAX ? maxlen - (uint32_t)P : SUB_BITS_MAX;
                 while (sb > 1u && (np << sb) > pool) --sb;
                 np_fit = (pool >> sb) < np ? (pool >> sb) : np;
+                sub_total = np_fit << sb;
+                // what the uniform tables leave unresolved, in units of 2^-15 of the tokens (prefixes without a table count
+                // as all of it: that case always goes per prefix)
+                uint32_t beyond = np_fit < np ? ~0u : 0u;
+#pragma nounroll
+                for (uint32_t l = 15u; l > (uint32_t)P + sb && beyond <= SUB_LONG_RATE; --l) {
+#if PZG_DEVICE_PASS
+                    const uint32_t cnt_l = read_lane(metav, l) & 0xffffu;
+#else
+                    const uint32_t cnt_l = meta->count[l];
+#endif
+                    beyond += cnt_l << (15u - l);
+                }
+                uniform = beyond <= SUB_LONG_RATE;
+            }
+            if (!uniform) {
+                // prefixes per depth (prefix q's depth: the largest l - P whose canonical range of length-l codes reaches it)
+                uint32_t per_depth[SUB_DEPTH_MAX + 1u];
+                for (uint32_t d = 0; d <= SUB_DEPTH_MAX; ++d) per_depth[d] = 0u;
+#pragma nounroll
+                for (uint32_t q0 = 0; q0 < np; q0 += PZG_WAVE) {
+                    const uint32_t c_p = covered_p + q0 + lane;
+                    const uint32_t dq = sub_depth<P>(meta, metav, c_p, q0 + lane < np);
+                    if (q0 + lane < np) lut[bitrev32(c_p) >> (32u - P)] = dq;  // (kept there until the K_SUB entries are written below)
+                    per_depth[0] += popc64(ballot(q0 + lane < np && dq == 0u));  // (a hole of an incomplete code: one K_LONG entry)
+#pragma nounroll
+                    for (uint32_t d = 1; d <= SUB_DEPTH_MAX; ++d) per_depth[d] += popc64(ballot(dq == d));
+                }
+                dcap = SUB_DEPTH_MAX;
+                for (;;) {
+                    sub_total = per_depth[0];
+                    for (uint32_t d = 1; d <= SUB_DEPTH_MAX; ++d) sub_total += per_depth[d] << (d < dcap ? d : dcap);
+                    if (sub_total <= pool || dcap == 1u) break;
+                    --dcap;
+                }
+                np_fit = np;
+                if (sub_total > pool) {  // (dcap == 1: two entries per prefix)
+                    np_fit = pool >> 1;
+                    sub_total = np_fit << 1;
+                }
             }
             if (TREE == TREE_LITLEN) {
-                lit_sub_used = np_fit << sb;
+                lit_sub_used = sub_total;
                 use_sub = np_fit >= SUB_MIN_PREFIXES ? 1u : 0u;
 #if defined(PZG_NO_SUB)
                 use_sub = 0u;  // (experiment: the one-level window code only)
 #endif
             }
 #pragma nounroll
-            for (uint32_t i0 = 0; i0 < (np_fit << sb); i0 += PZG_WAVE) {
+            for (uint32_t i0 = 0; i0 < sub_total; i0 += PZG_WAVE) {
                 const uint32_t i = i0 + lane;
-                if (i < (np_fit << sb)) L.sub[sub0 + i] = mk_stop(0, K_LONG, 0);
+                if (i < sub_total) L.sub[sub0 + i] = mk_stop(0, K_LONG, 0);
             }
         }
         wave_sync();
@@ -907,8 +990,8 @@ struct Decoder {
                 if (e15 == 0u) {
                     ent = mk_stop(1, K_EMPTY_TREE, 0);
                 } else if ((c_p << (15u - P)) < e15) {
-                    ent = (TREE != TREE_CODELEN && c_p - covered_p < np_fit) ? (mk_stop(sb, K_SUB, sub0 + ((c_p - covered_p) << sb)) | ENT_SUB)
-                                                                           : mk_stop(0, K_LONG, 0);
+                    ent = (TREE != TREE_CODELEN && uniform && c_p - covered_p < np_fit) ? (mk_stop(sb, K_SUB, sub0 + ((c_p - covered_p) << sb)) | ENT_SUB)
+                                                                                      : mk_stop(0, K_LONG, 0);
                 } else {
                     uint32_t d = (uint32_t)P;  // smallest d whose d-bit prefix is at or past the end of all codes
 #pragma unroll
@@ -916,7 +999,26 @@ struct Decoder {
                         if (((c_p >> ((uint32_t)P - t)) << (15u - t)) >= e15) d = t;
                     ent = mk_stop(d, K_EMPTY_BRANCH, 0);
                 }
-                if (idx < (1u << P) && c_p >= covered_p) lut[idx] = ent;
+                // (the prefixes that get a second-level table hold their depth for the moment: not touched here)
+                if (idx < (1u << P) && c_p >= covered_p && !(TREE != TREE_CODELEN && !uniform && c_p - covered_p < np_fit)) lut[idx] = ent;
+            }
+        }
+        if (TREE != TREE_CODELEN && !uniform && np_fit != 0u) {  // the K_SUB entries, in canonical order of the prefixes (offsets = running sum of the table sizes)
+            uint32_t run = 0;
+#pragma nounroll
+            for (uint32_t q0 = 0; q0 < np_fit; q0 += PZG_WAVE) {
+                const uint32_t q = q0 + lane, c_p = covered_p + q;
+                const uint32_t idx = bitrev32(c_p) >> (32u - P);
+                const uint32_t dq = lut[q < np_fit ? idx : 0u];  // its depth, left there by the counting pass
+                const uint32_t depth = dq < dcap ? dq : dcap;
+                const uint32_t size = q < np_fit ? 1u << depth : 0u;
+                const uint32_t incl = wave_iscan_add(size);
+                if (q < np_fit) lut[idx] = mk_stop(depth, K_SUB, sub0 + run + incl - size) | ENT_SUB;
+#if PZG_DEVICE_PASS
+                run += read_lane(incl, 63u);
+#else
+                run += incl;
+#endif
             }
         }
         wave_sync();
@@ -951,11 +1053,15 @@ struct Decoder {
                 } else if (TREE != TREE_CODELEN && np_fit != 0u) {
                     const uint32_t rl = len - (uint32_t)P;   // bits of the code past its P-bit prefix
                     const uint32_t pfx = (c >> rl) - covered_p;
-                    if (rl <= sb && pfx < np_fit) {
-                        const uint32_t ent = TREE == TREE_LITLEN ? litlen_entry(s, len) : dist_entry(s, len);
-                        const uint32_t rev = bitrev32(c & ((1u << rl) - 1u)) >> (32u - rl);  // those bits in stream order
+                    if (pfx < np_fit) {
+                        const uint32_t ps = lut[bitrev32(c >> rl) >> (32u - P)];  // the prefix' K_SUB entry: its table's depth and place
+                        const uint32_t depth = ent_n(ps);
+                        if (rl <= depth) {
+                            const uint32_t ent = TREE == TREE_LITLEN ? litlen_entry(s, len) : dist_entry(s, len);
+                            const uint32_t rev = bitrev32(c & ((1u << rl) - 1u)) >> (32u - rl);  // those bits in stream order
 #pragma nounroll
-                        for (uint32_t idx = rev; idx < (1u << sb); idx += (1u << rl)) L.sub[sub0 + (pfx << sb) + idx] = ent;
+                            for (uint32_t idx = rev; idx < (1u << depth); idx += (1u << rl)) L.sub[ent_sub_index(ps) + idx] = ent;
+                        }
                     }
                 }
             }
@@ -1736,6 +1842,11 @@ struct Decoder {
     PZG_FN uint32_t hot_loop(LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TK1, uint64_t &S0, uint64_t &S1, uint32_t &k0, uint32_t &k1)
     {
         uint32_t why;
+#if PZG_DEVICE_PASS && PZG_HOT_ALIGN
+        // the loop starts on a fixed boundary: the kernel is bound by instruction fetch, and where the loop's blocks fall
+        // within the fetch blocks would otherwise move (by +-1.5 % of the whole kernel) with every edit of the code before it
+        asm volatile(".p2align " PZG_STR(PZG_HOT_ALIGN));
+#endif
         for (;;) {
             if (qn < QHIGH) {
                 if (__builtin_expect(!br.window2_ok(), 0)) {

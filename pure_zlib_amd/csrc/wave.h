@@ -124,6 +124,20 @@ PZG_FN uint32_t wave_sum(uint32_t x)
 #endif
 }
 
+// inclusive prefix sum over the lanes of a per-lane value (the one-lane host model: the value itself)
+PZG_FN uint32_t wave_iscan_add(uint32_t x)
+{
+#if PZG_DEVICE_PASS
+    x += dpp_zero<0x111, 0xf>(x);
+    x += dpp_zero<0x112, 0xf>(x);
+    x += dpp_zero<0x114, 0xf>(x);
+    x += dpp_zero<0x118, 0xf>(x);
+    x += dpp_zero<0x142, 0xa>(x);
+    x += dpp_zero<0x143, 0xc>(x);
+#endif
+    return x;
+}
+
 PZG_FN uint32_t wave_max(uint32_t x)
 {
 #if PZG_DEVICE_PASS
