@@ -243,7 +243,8 @@ continueDecoder inc = do
   out <- mallocForeignPtrBytes feedRoom :: IO (ForeignPtr Word8)
   (st, produced, used, chunks, det) <-
     withForeignPtr (incDec inc) $ \pd -> withForeignPtr out $ \pout ->
-    SU.unsafeUseAsCStringLen t $ \(pin, tlen) ->
+    -- (an empty tail is S.empty, whose pointer is NULL on bytestring >= 0.11: hand over one dummy byte with in_len = 0)
+    SU.unsafeUseAsCStringLen (if S.null t then S.singleton 0 else t) $ \(pin, _) -> let tlen = S.length t in
     alloca $ \pioff -> alloca $ \pilen -> alloca $ \pooff -> alloca $ \pocap -> alloca $ \polen ->
     alloca $ \pst -> allocaArray 2 $ \pdet -> alloca $ \pused -> alloca $ \pchunks -> do
       poke pioff 0

@@ -21,6 +21,16 @@
  * Ownership: the caller allocates and owns every buffer; the library retains no
  * caller pointer past return (except with PZG_ASYNC, until pzg_sync()).
  * No exception crosses the boundary.
+ *
+ * Lifetimes: the reference's ZlibDecoder is a garbage-collected closure (Monad.hs:163-167,185-197): it can be dropped
+ * at any time, in any order, and cannot dangle.  The same holds here.  A pzg_ctx is reference counted: the handle
+ * pzg_init returns is one reference, every live pzg_decoder holds another.  pzg_shutdown() waits for the work
+ * enqueued through the handle, drops the caller's reference and invalidates the handle (every later call on it fails
+ * with PZG_RC_BAD_ARG instead of touching freed memory, for as long as a decoder keeps the context alive; after that
+ * the handle is dangling like any freed pointer).  Decoders created from it stay fully usable after pzg_shutdown --
+ * pzg_decoder_feed / _reset / _destroy in any order -- and the device resources go with the last
+ * pzg_decoder_destroy().  pzg_shutdown() then pzg_decoder_destroy(), or the reverse, are both correct; finalisers
+ * (GHC ForeignPtr, Python __del__, C++ shared_ptr) may therefore run in whatever order the collector picks.
  */
 #ifndef PZG_H
 #define PZG_H
@@ -101,6 +111,8 @@ int  pzg_init(int device, pzg_ctx **out);
  * are independent, so nothing crosses between devices (no collective).  PZG_DEVICE_PTRS calls need a one-device context. */
 int  pzg_init_mask(uint32_t device_mask, pzg_ctx **out);
 int  pzg_device_count(pzg_ctx *ctx);  /* devices (shards) of the context */
+/* Drop the caller's reference (see "Lifetimes" above): synchronises, invalidates the handle, frees everything unless
+ * decoders are still alive -- then the last pzg_decoder_destroy() frees it.  NULL is ignored. */
 void pzg_shutdown(pzg_ctx *ctx);
 
 /* Make the context launch on an existing HIP stream (e.g. a framework's current stream) instead of
@@ -168,7 +180,8 @@ int pzg_decompress_many_dict(pzg_ctx *ctx,
  * idx[0..m) (idx = NULL: all n, m ignored) -- one launch, one wavefront per decoder -- as far as their input and
  * output room go.  For decoder k = idx[j]:
  *   in_base + in_off[j] .. + in_len[j]   the bytes the last call did not consume (from its in_used on) followed by
- *                                        the new input; final_in[j] != 0 (array may be NULL): no more input will follow
+ *                                        the new input; final_in[j] != 0 (array may be NULL): no more input will follow;
+ *                                        in_base may be NULL when every in_len[j] is 0
  *   out_base + out_off[j] .. + out_cap[j]  room for the bytes this call delivers (out_cap >= 4096); out_len[j] of them
  *   state[j]     PZG_DEC_NEED_INPUT  suspended on input: the reference's NeedMore
  *                PZG_DEC_OUT_FULL    suspended on room: call again with in_base + in_used[j] onward
@@ -182,8 +195,8 @@ int pzg_decompress_many_dict(pzg_ctx *ctx,
  * Host pointers only.  Nothing is re-decoded: a feed costs what its new input costs.
  */
 typedef struct pzg_decoder pzg_decoder;
-int  pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out);
-void pzg_decoder_destroy(pzg_decoder *dec);
+int  pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out);  /* takes a reference on ctx */
+void pzg_decoder_destroy(pzg_decoder *dec);  /* legal before or after pzg_shutdown(ctx); NULL is ignored */
 int  pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m);  /* those decoders start a new stream */
 int  pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m,
                       const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len, const uint8_t *final_in,

@@ -111,6 +111,10 @@ struct Shard {
 }  // namespace
 
 struct pzg_ctx {
+    // Lifetime (include/pzg.h "Lifetimes"): the caller's handle is one reference, every live pzg_decoder another; the
+    // context is freed when the last of them goes.  `closed` is set by pzg_shutdown: calls on the handle after that fail.
+    std::atomic<int> refs{1};
+    std::atomic<bool> closed{false};
     std::vector<std::unique_ptr<Shard>> shards;
     int ring_bits = PZG_DEFAULT_RING_BITS;
     std::mutex err_mu;
@@ -267,6 +271,15 @@ int ctx_create(const std::vector<int> &devices, pzg_ctx **out)
     *out = ctx;
     return PZG_RC_OK;
 }
+
+void ctx_unref(pzg_ctx *ctx)
+{
+    if (ctx->refs.fetch_sub(1) != 1) return;
+    for (auto &s : ctx->shards) shard_destroy(*s);
+    delete ctx;
+}
+
+inline bool ctx_live(const pzg_ctx *ctx) { return ctx && !ctx->closed.load(std::memory_order_acquire); }
 
 // ---- the device-pointer path: everything already lives on shard 0's device -------------------------------------
 int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
@@ -754,18 +767,24 @@ int pzg_init_mask(uint32_t device_mask, pzg_ctx **out)
     }
 }
 
-int pzg_device_count(pzg_ctx *ctx) { return ctx ? (int)ctx->shards.size() : 0; }
+int pzg_device_count(pzg_ctx *ctx) { return ctx_live(ctx) ? (int)ctx->shards.size() : 0; }
 
 void pzg_shutdown(pzg_ctx *ctx)
 {
     if (!ctx) return;
-    for (auto &s : ctx->shards) shard_destroy(*s);
-    delete ctx;
+    if (ctx->closed.exchange(true)) return;  // (a second shutdown while decoders keep the context alive: nothing to drop)
+    // quiet before the handle goes: nothing enqueued through it may still be running on caller memory
+    for (auto &s : ctx->shards) {
+        std::lock_guard<std::mutex> g(s->mu);
+        if (hipSetDevice(s->device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
+        s->stream = s->own_stream;  // a borrowed stream (pzg_set_stream) may not outlive this call on the caller's side
+    }
+    ctx_unref(ctx);  // live decoders hold their own references: the last pzg_decoder_destroy frees the context
 }
 
 int pzg_set_stream(pzg_ctx *ctx, void *hip_stream)
 {
-    if (!ctx) return PZG_RC_BAD_ARG;
+    if (!ctx_live(ctx)) return PZG_RC_BAD_ARG;
     Shard &sh = *ctx->shards[0];
     std::lock_guard<std::mutex> g(sh.mu);
     sh.stream = (hipStream_t)hip_stream;  // NULL = the default (null) stream
@@ -774,7 +793,7 @@ int pzg_set_stream(pzg_ctx *ctx, void *hip_stream)
 
 int pzg_reset_stream(pzg_ctx *ctx)
 {
-    if (!ctx) return PZG_RC_BAD_ARG;
+    if (!ctx_live(ctx)) return PZG_RC_BAD_ARG;
     Shard &sh = *ctx->shards[0];
     std::lock_guard<std::mutex> g(sh.mu);
     sh.stream = sh.own_stream;
@@ -783,7 +802,7 @@ int pzg_reset_stream(pzg_ctx *ctx)
 
 int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
 {
-    if (!ctx) return PZG_RC_BAD_ARG;
+    if (!ctx_live(ctx)) return PZG_RC_BAD_ARG;
     if (option == PZG_OPT_RING_BITS && value >= 11 && value <= 15) {
         ctx->ring_bits = (int)value;
         return PZG_RC_OK;
@@ -793,7 +812,7 @@ int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
 
 int pzg_sync(pzg_ctx *ctx)
 {
-    if (!ctx) return PZG_RC_BAD_ARG;
+    if (!ctx_live(ctx)) return PZG_RC_BAD_ARG;
     for (auto &s : ctx->shards) {
         std::lock_guard<std::mutex> g(s->mu);
         HIP_TRY(ctx, hipSetDevice(s->device));
@@ -816,7 +835,7 @@ int pzg_decompress_many_dict(pzg_ctx *ctx, const uint8_t *in_base, const uint64_
                              const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status, uint32_t *detail,
                              uint64_t *in_used, uint32_t *adler, uint32_t n, uint32_t flags)
 {
-    if (!ctx) return PZG_RC_BAD_ARG;
+    if (!ctx_live(ctx)) return PZG_RC_BAD_ARG;
     const bool with_dict = dict_base && dict_off && dict_len;
     if (with_dict && (flags & PZG_GZIP)) return PZG_RC_BAD_ARG;  // (preset dictionaries are a zlib-container notion)
     if (n == 0) return PZG_RC_OK;
@@ -883,21 +902,26 @@ int pzg_decompress_many_dict(pzg_ctx *ctx, const uint8_t *in_base, const uint64_
             load[best] += out_cap[i] + in_len[i] + 4096;  // (+ a per-stream constant: tiny streams are not free)
         }
         std::vector<int> rcs(S, PZG_RC_OK);
+        auto run_shard = [&](size_t s) noexcept {
+            try {
+                rcs[s] = host_path(ctx, *ctx->shards[s], b, part[s].data(), (uint32_t)part[s].size());
+            } catch (...) {
+                rcs[s] = PZG_RC_NO_MEMORY;
+            }
+        };
         std::vector<std::thread> th;
-        for (size_t s = 1; s < S; ++s)
-            th.emplace_back([&, s] {
-                try {
-                    rcs[s] = host_path(ctx, *ctx->shards[s], b, part[s].data(), (uint32_t)part[s].size());
-                } catch (...) {
-                    rcs[s] = PZG_RC_NO_MEMORY;
-                }
-            });
-        try {
-            rcs[0] = host_path(ctx, *ctx->shards[0], b, part[0].data(), (uint32_t)part[0].size());
-        } catch (...) {
-            rcs[0] = PZG_RC_NO_MEMORY;
+        th.reserve(S - 1);  // (emplace_back below cannot reallocate: a throw can only come from the thread's creation)
+        size_t started = 1;
+        for (; started < S; ++started) {
+            try {
+                th.emplace_back(run_shard, started);
+            } catch (...) {  // no more threads to be had: this thread runs the remaining shards itself, one after the other
+                break;
+            }
         }
-        for (auto &t : th) t.join();
+        run_shard(0);
+        for (size_t s = started; s < S; ++s) run_shard(s);
+        for (auto &t : th) t.join();  // always: the started threads write into the caller's buffers
         for (int rc : rcs)
             if (rc != PZG_RC_OK) return rc;
         return PZG_RC_OK;
@@ -916,7 +940,8 @@ int pzg_decompress_many_dict(pzg_ctx *ctx, const uint8_t *in_base, const uint64_
 }  // extern "C"
 
 struct pzg_decoder {
-    pzg_ctx *ctx = nullptr;
+    pzg_ctx *ctx = nullptr;  // holds one reference (ctx_unref in pzg_decoder_destroy): never dangles
+    int device = 0;
     uint32_t n = 0;
     size_t stride = 0;
     uint8_t *d_state = nullptr;  // n x stride: ResumeState + LDS image per decoder
@@ -930,26 +955,37 @@ extern "C" {
 
 int pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out)
 {
-    if (!ctx || !out || n == 0 || ctx->shards.size() != 1) return PZG_RC_BAD_ARG;
-    *out = nullptr;
+    if (out) *out = nullptr;
+    if (!ctx_live(ctx) || !out || n == 0 || ctx->shards.size() != 1) return PZG_RC_BAD_ARG;
+    pzg_decoder *d = nullptr;
     try {
         Shard &sh = *ctx->shards[0];
         HIP_TRY(ctx, hipSetDevice(sh.device));
-        std::unique_ptr<pzg_decoder> d(new pzg_decoder());
+        d = new pzg_decoder();
+        ctx->refs.fetch_add(1);
         d->ctx = ctx;
+        d->device = sh.device;
         d->n = n;
         d->stride = pzg::resume_state_bytes();
-        if (hipMalloc((void **)&d->d_state, d->stride * (size_t)n) != hipSuccess) return PZG_RC_NO_MEMORY;
-        if (hipMalloc((void **)&d->d_counter, 256) != hipSuccess) {
-            (void)hipFree(d->d_state);
-            return PZG_RC_NO_MEMORY;
+        // every failure from here on leaves through pzg_decoder_destroy: nothing allocated so far is leaked
+        int rc = PZG_RC_OK;
+        hipError_t e;
+        if (hipMalloc((void **)&d->d_state, d->stride * (size_t)n) != hipSuccess || hipMalloc((void **)&d->d_counter, 256) != hipSuccess)
+            rc = PZG_RC_NO_MEMORY;
+        else if ((e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking)) != hipSuccess)
+            rc = hip_fail(ctx, e, "hipStreamCreateWithFlags");
+        else if ((e = hipMemsetAsync(d->d_state, 0, d->stride * (size_t)n, d->stream)) != hipSuccess)
+            rc = hip_fail(ctx, e, "hipMemsetAsync");
+        else if ((e = hipStreamSynchronize(d->stream)) != hipSuccess)
+            rc = hip_fail(ctx, e, "hipStreamSynchronize");
+        if (rc != PZG_RC_OK) {
+            pzg_decoder_destroy(d);
+            return rc;
         }
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-        HIP_TRY(ctx, hipMemsetAsync(d->d_state, 0, d->stride * (size_t)n, d->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(d->stream));
-        *out = d.release();
+        *out = d;
         return PZG_RC_OK;
     } catch (...) {
+        if (d) pzg_decoder_destroy(d);
         return PZG_RC_NO_MEMORY;
     }
 }
@@ -957,14 +993,16 @@ int pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out)
 void pzg_decoder_destroy(pzg_decoder *dec)
 {
     if (!dec) return;
-    (void)hipSetDevice(dec->ctx->shards[0]->device);
+    (void)hipSetDevice(dec->device);
     if (dec->stream) (void)hipStreamSynchronize(dec->stream);
     for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta})
         if (a->p) (void)hipFree(a->p);
     if (dec->d_state) (void)hipFree(dec->d_state);
     if (dec->d_counter) (void)hipFree(dec->d_counter);
     if (dec->stream) (void)hipStreamDestroy(dec->stream);
+    pzg_ctx *ctx = dec->ctx;
     delete dec;
+    if (ctx) ctx_unref(ctx);  // the last reference frees a context whose handle pzg_shutdown has already dropped
 }
 
 int pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m)
@@ -972,7 +1010,7 @@ int pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m)
     if (!dec) return PZG_RC_BAD_ARG;
     pzg_ctx *ctx = dec->ctx;
     std::lock_guard<std::mutex> g(dec->mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->shards[0]->device));
+    HIP_TRY(ctx, hipSetDevice(dec->device));
     if (!idx) {
         HIP_TRY(ctx, hipMemsetAsync(dec->d_state, 0, dec->stride * (size_t)dec->n, dec->stream));
     } else {
@@ -989,7 +1027,7 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                      const uint8_t *final_in, uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
                      int32_t *state, uint32_t *detail, uint64_t *in_used, uint32_t *chunks, uint32_t *adler)
 {
-    if (!dec || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !state || !in_used || !chunks)
+    if (!dec || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !state || !in_used || !chunks)
         return PZG_RC_BAD_ARG;
     pzg_ctx *ctx = dec->ctx;
     if (!idx) m = dec->n;
@@ -999,6 +1037,7 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
             if (idx && idx[j] >= dec->n) return PZG_RC_BAD_ARG;
             if (out_cap[j] < 4096u || (out_cap[j] >> 40) || (in_len[j] >> 40)) return PZG_RC_BAD_ARG;
             if (in_off[j] + in_len[j] < in_off[j] || out_off[j] + out_cap[j] < out_off[j]) return PZG_RC_BAD_ARG;
+            if (in_len[j] && !in_base) return PZG_RC_BAD_ARG;  // (in_base may be NULL when no decoder has input: an empty tail)
         }
         if (idx) {  // a decoder may appear once per call (each is continued by one wave)
             std::vector<uint32_t> seen(idx, idx + m);
@@ -1119,7 +1158,7 @@ int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len, uint8_t *ou
 
 int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *out, uint32_t flags)
 {
-    if (!ctx || !out || (!buf && len)) return PZG_RC_BAD_ARG;
+    if (!ctx_live(ctx) || !out || (!buf && len)) return PZG_RC_BAD_ARG;
     if ((flags & PZG_ASYNC) && !(flags & PZG_DEVICE_PTRS)) return PZG_RC_BAD_ARG;
     try {
         Shard &sh = *ctx->shards[0];
@@ -1157,7 +1196,7 @@ int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init, u
 int pzg_adler32_many(pzg_ctx *ctx, const uint8_t *base, const uint64_t *off, const uint64_t *len, uint32_t *out, uint32_t n,
                      uint32_t flags)
 {
-    if (!ctx || !base || !off || !len || !out) return PZG_RC_BAD_ARG;
+    if (!ctx_live(ctx) || !base || !off || !len || !out) return PZG_RC_BAD_ARG;
     if (!(flags & PZG_DEVICE_PTRS) || ctx->shards.size() != 1) return PZG_RC_BAD_ARG;  // device-resident batches only
     if (n == 0) return PZG_RC_OK;
     Shard &sh = *ctx->shards[0];
@@ -1173,7 +1212,7 @@ int pzg_adler32_many(pzg_ctx *ctx, const uint8_t *base, const uint64_t *off, con
 
 double pzg_last_kernel_ms(pzg_ctx *ctx)
 {
-    if (!ctx) return -1.0;
+    if (!ctx_live(ctx)) return -1.0;
     Shard &sh = *ctx->shards[0];
     std::lock_guard<std::mutex> g(sh.mu);
     if (!sh.timed) return -1.0;

@@ -271,7 +271,7 @@ class ZlibDecoder {
             static const uint8_t none = 0;
             const int rc = pzg_decoder_feed(dec_.get(), nullptr, 1, tail_.empty() ? &none : (const uint8_t *)tail_.data(), &in_off, &in_len,
                                             nullptr, out.data(), &out_off, &out_cap, &out_len, &st, det, &in_used, &chunks, nullptr);
-            if (rc != PZG_RC_OK) throw std::runtime_error(std::string("pzg_decoder_feed: ") + pzg_last_error(ctx_->handle()));
+            if (rc != PZG_RC_OK) throw std::runtime_error(std::string("pzg_decoder_feed: ") + pzg_strerror(rc));
             pending_.append((const char *)out.data(), out_len);
             tail_.erase(0, in_used);
             device_chunks_ = chunks;
@@ -297,7 +297,9 @@ class ZlibDecoder {
     }
     const DecompressionError &error() const { return error_; }
 
-    explicit ZlibDecoder(Context &ctx = Context::shared()) : ctx_(&ctx)
+    // The decoder takes its own reference on the library's context (include/pzg.h "Lifetimes"): like the reference's
+    // closure (Monad.hs:163-167) it may outlive the Context object it was made from and be dropped in any order.
+    explicit ZlibDecoder(Context &ctx = Context::shared())
     {
         pzg_decoder *d = nullptr;
         const int rc = pzg_decoder_create(ctx.handle(), 1, &d);
@@ -325,7 +327,6 @@ class ZlibDecoder {
             state_ = terminal_;
         }
     }
-    Context *ctx_;
     std::shared_ptr<pzg_decoder> dec_;
     State state_ = NeedMore, terminal_ = NeedMore;
     ByteString tail_, all_, pending_, cur_;

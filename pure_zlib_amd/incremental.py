@@ -13,6 +13,7 @@ in exactly the reference's order (tests compare the event trace with the oracle'
 decoders per launch; `decompress_incremental()` is the reference's single-decoder entry point on a pool of one.
 Nothing here inflates on the CPU.
 """
+import functools
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -81,9 +82,17 @@ class DecoderPool:
         self._closed = [False] * n
 
     def close(self):
+        """pzg_decoder_destroy.  Legal before or after the Context is closed: the decoders hold their own reference on
+        the library's context (include/pzg.h "Lifetimes"), as a ZlibDecoder closure keeps what it needs alive."""
         if self._h:
             self._L.pzg_decoder_destroy(self._h)
             self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def __del__(self):
         try:
@@ -103,6 +112,8 @@ class DecoderPool:
         for k, c in zip(ks, chunks):
             if self._closed[k]:
                 raise ValueError("this decoder has finished")
+            if not self._h:
+                raise ValueError("this DecoderPool has been closed")
             if len(c) == 0 and not final:
                 results[k] = NeedMore(self, k)  # S.uncons = Nothing: ask again (Monad.hs:194)
             else:
@@ -159,16 +170,20 @@ class DecoderPool:
         return [results[k] for k in ks]
 
     def _chain(self, k, events):
-        def make(i):
-            e = events[i]
-            if e[0] == "Chunk":
-                return Chunk(e[1], lambda: make(i + 1))
-            if e[0] == "NeedMore":
-                return NeedMore(self, k)
-            if e[0] == "Done":
-                return Done()
-            return DecompError(e[1])
-        return make(0)
+        return _state_at(self, k, events, 0)
+
+
+def _state_at(pool: "DecoderPool", k: int, events, i: int):
+    """The constructor for events[i]; a Chunk's continuation is a partial of this module-level function (no closure
+    that refers to itself: a dropped decoder is freed by reference counting at once, not by a later cycle collection)."""
+    e = events[i]
+    if e[0] == "Chunk":
+        return Chunk(e[1], functools.partial(_state_at, pool, k, events, i + 1))
+    if e[0] == "NeedMore":
+        return NeedMore(pool, k)
+    if e[0] == "Done":
+        return Done()
+    return DecompError(e[1])
 
 
 def decompress_incremental(ctx: Optional[Context] = None):

@@ -156,9 +156,17 @@ class Context:
         return int(self._L.pzg_device_count(self._h))
 
     def close(self):
+        """pzg_shutdown: drops this handle.  DecoderPools made from the context stay usable and free the device state
+        when the last of them is closed (the library counts references; include/pzg.h "Lifetimes")."""
         if self._h:
             self._L.pzg_shutdown(self._h)
             self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def __del__(self):
         try:
@@ -205,6 +213,8 @@ class Context:
         if n == 0:
             return out_len, status, detail, in_used, adler
         if dict_buf is not None:  # extension: one preset dictionary extent per stream (length 0 = none)
+            if gzip:  # (preset dictionaries are a zlib-container notion: the C ABI rejects the combination too)
+                raise ValueError("gzip=True and preset dictionaries cannot be combined")
             dict_off = np.ascontiguousarray(dict_off, dtype=np.uint64)
             dict_len = np.ascontiguousarray(dict_len, dtype=np.uint64)
             rc = self._L.pzg_decompress_many_dict(

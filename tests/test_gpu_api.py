@@ -145,3 +145,60 @@ def test_cxx_threads_overlap_on_one_context():
     assert out.returncode == 0 and "160 calls from 8 threads, 0 bad" in out.stdout, out.stdout + out.stderr
     speedup = float(out.stdout.split("speed-up over one thread:")[1].split("x")[0])
     assert speedup > 1.15, out.stdout
+
+
+def _build_cxx(name, extra=()):
+    exe = os.path.join(ROOT, "tests", "cxx", name)
+    src = os.path.join(ROOT, "tests", "cxx", name + ".cpp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", *extra, src, "-o", exe, "-L" + os.path.join(ROOT, "pure_zlib_amd"),
+                           "-lpzg", "-Wl,-rpath," + os.path.join(ROOT, "pure_zlib_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cxx_decoder_and_context_lifetimes_in_any_order():
+    """include/pzg.h "Lifetimes" (the reference's ZlibDecoder is a GC'd closure, Monad.hs:163-197: it can be dropped at any
+    time, in any order): decoder before context, context before decoder, a decoder USED after pzg_shutdown, the
+    invalidated handle refused.  Round 2's pzg_decoder_destroy read a freed context here."""
+    exe = _build_cxx("lifetimes")
+    ref = os.path.join(ROOT, "tests", "golden", "ref")
+    out = subprocess.run([exe, os.path.join(ref, "rfctest2.z"), os.path.join(ref, "rfctest2.gold")], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "lifetimes ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_python_pool_outlives_its_context(gpu_ctx, oracle):
+    """The Python mirror: a DecoderPool keeps decoding after Context.close(), closes after it, and a dropped pool is freed by
+    reference counting alone (no self-referential closure left in the Chunk chain)."""
+    import gc
+    import weakref
+    import pure_zlib_amd as P
+    from pure_zlib_amd.incremental import Chunk, DecoderPool, Done
+    ctx = P.Context(0)
+    pool = DecoderPool(1, ctx)
+    z = zlib.compress(corpus.zipf_text(150000, 5), 6)
+    ctx.close()
+    st, got = pool.start(0).feed(z), b""
+    while isinstance(st, Chunk):
+        got += st.chunk
+        st = st.next()
+    assert isinstance(st, Done) and got == zlib.decompress(z)
+    with pytest.raises(Exception):
+        P.decompress(z, ctx=ctx)  # the closed handle is refused, not dereferenced
+    gc.disable()
+    try:
+        w = weakref.ref(pool)
+        st2 = DecoderPool(1, gpu_ctx).start(0).feed(z)  # a chain of Chunks that is simply dropped
+        w2 = weakref.ref(st2._rest.args[0])
+        del pool, st, st2
+        assert w() is None and w2() is None, "a DecoderPool is kept alive by a reference cycle"
+    finally:
+        gc.enable()
+
+
+def test_smoke_exits_cleanly_in_a_child_process():
+    """smoke() printed its OK line and then died of SIGSEGV at interpreter exit.  Run it as the driver does -- a
+    fresh interpreter -- and look at the exit code."""
+    import sys
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as e; e.smoke()"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
