@@ -2344,7 +2344,8 @@ struct Decoder {
         if (br.avail() < 16) return fail(ST_TRUNCATED, 0, 0);
         const uint32_t hw = br.peek32();
         const uint32_t cmf = hw & 0xffu, flg = (hw >> 8) & 0xffu;
-        if (RES && (flg & 0x20u) && br.avail() < 48) return fail(ST_TRUNCATED, 0, 0);  // (resumable: the header is taken whole)
+        // (resumable instance: running out of input below -- the DICTID of an FDICT header -- suspends at the start of the
+        // header, which is then read again as a whole; the three checks on CMF/FLG come first, as in the reference)
         br.drop(16);
         if (((cmf << 8) | flg) % 31u != 0u) return fail(ST_HDR_FCHECK, (cmf << 8) | flg, 0);
         if ((cmf & 15u) != 8u) return fail(ST_HDR_METHOD, cmf & 15u, 0);

@@ -51,7 +51,8 @@ static int run_stream(pzg_decoder *dec, const std::vector<uint8_t> &z, const std
         uint64_t out_len = 0, in_used = 0;
         uint32_t det[2] = {0, 0}, chunks = 0;
         // (an empty tail: in_base may be NULL when no decoder has input)
-        const int rc = pzg_decoder_feed(dec, nullptr, 1, tail.empty() ? nullptr : tail.data(), &in_off, &in_len, nullptr, out.data(), &out_off,
+        const uint32_t idx0 = 0;  // (decoder 0 of the pool; idx = NULL would mean all of them)
+        const int rc = pzg_decoder_feed(dec, &idx0, 1, tail.empty() ? nullptr : tail.data(), &in_off, &in_len, nullptr, out.data(), &out_off,
                                         &out_cap, &out_len, &st, det, &in_used, &chunks, nullptr);
         CHECK(rc == PZG_RC_OK);
         got.insert(got.end(), out.begin(), out.begin() + out_len);

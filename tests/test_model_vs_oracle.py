@@ -231,6 +231,31 @@ def test_model_incremental_event_trace(model_lib, oracle):
             assert bytes(dec.total) == oo
 
 
+def test_model_incremental_bad_header_with_fdict_bit(model_lib, oracle):
+    """Zlib.hs:53-67: CMF and FLG are read and checked (FCHECK, method, window) before anything else; a bad header whose FDICT
+    bit is set is a DecompError after two bytes, not a NeedMore waiting for a DICTID."""
+    def hdr(cmf, flg_hi):  # FLG with FDICT set and a valid FCHECK
+        flg = (flg_hi & 0xc0) | 0x20
+        flg += (31 - ((cmf << 8) | flg) % 31) % 31
+        return bytes([cmf, flg])
+    good = hdr(0x78, 0x80)
+    assert (good[0] * 256 + good[1]) % 31 == 0 and good[1] & 0x20
+    cases = [bytes([0x78, 0x21]),          # FCHECK fails (0x7821 % 31 != 0), FDICT bit set
+             hdr(0x77, 0x80),              # method 7
+             hdr(0x88, 0x80),              # window 8
+             good,                         # a sound FDICT header: NeedMore until the DICTID and more have come
+             good + b"\x01\x02\x03"]
+    for z in cases:
+        for step in (1, 2, 5):
+            pieces = [z[i:i + step] for i in range(0, len(z), step)]
+            eo, _ro, _oo = oracle.trace(pieces)
+            dec = ModelDecoder(model_lib, 4096)
+            for p in pieces:
+                if not dec.feed(p):
+                    break
+            assert dec.events == eo, (z.hex(), step, dec.events, eo)
+
+
 def test_model_preset_dictionary(model_lib, oracle):
     """PZG_FDICT extension: dictionary installed as history (ring 15 instance) against zlib and the oracle."""
     for seed in range(40):
