@@ -42,6 +42,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: these declarations are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#define PZG_API __attribute__((visibility("default")))
+#else
+#define PZG_API
+#endif
+
 #define PZG_VERSION_MAJOR 0
 #define PZG_VERSION_MINOR 2
 
@@ -103,24 +110,24 @@ typedef struct pzg_ctx pzg_ctx;
 
 /* Create a context on HIP device `device` (0-based).  One HIP stream + grow-only device
  * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device. */
-int  pzg_init(int device, pzg_ctx **out);
+PZG_API int  pzg_init(int device, pzg_ctx **out);
 /* decompressMany over SEVERAL devices of one node (API of Zlib.hs:32-35, batched): bit d of `device_mask`
  * selects HIP device d, 0 selects every visible device.  One call of pzg_decompress_many() with HOST pointers then
  * partitions the streams over the devices (longest-processing-time-first by capacity), one host thread, HIP stream set
  * and staging arenas per device, and every result lands in the caller's own out_off[] / status[] slots: the streams
  * are independent, so nothing crosses between devices (no collective).  PZG_DEVICE_PTRS calls need a one-device context. */
-int  pzg_init_mask(uint32_t device_mask, pzg_ctx **out);
-int  pzg_device_count(pzg_ctx *ctx);  /* devices (shards) of the context */
+PZG_API int  pzg_init_mask(uint32_t device_mask, pzg_ctx **out);
+PZG_API int  pzg_device_count(pzg_ctx *ctx);  /* devices (shards) of the context */
 /* Drop the caller's reference (see "Lifetimes" above): synchronises, invalidates the handle, frees everything unless
  * decoders are still alive -- then the last pzg_decoder_destroy() frees it.  NULL is ignored. */
-void pzg_shutdown(pzg_ctx *ctx);
+PZG_API void pzg_shutdown(pzg_ctx *ctx);
 
 /* Make the context launch on an existing HIP stream (e.g. a framework's current stream) instead of
  * its own.  `hip_stream` is a hipStream_t passed as void*; NULL means HIP's default (null) stream.
  * pzg_reset_stream() goes back to the context's own non-blocking stream. */
-int  pzg_set_stream(pzg_ctx *ctx, void *hip_stream);
-int  pzg_reset_stream(pzg_ctx *ctx);
-int  pzg_sync(pzg_ctx *ctx);
+PZG_API int  pzg_set_stream(pzg_ctx *ctx, void *hip_stream);
+PZG_API int  pzg_reset_stream(pzg_ctx *ctx);
+PZG_API int  pzg_sync(pzg_ctx *ctx);
 
 /* Tuning options.
  * PZG_OPT_RING_BITS: log2 of the LDS ring each stream-wave keeps of its most recent output.
@@ -130,7 +137,7 @@ int  pzg_sync(pzg_ctx *ctx);
  *   Results are bit-identical for every value.  Default: PZG_DEFAULT_RING_BITS. */
 #define PZG_OPT_RING_BITS 1
 #define PZG_DEFAULT_RING_BITS 11
-int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
+PZG_API int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
 
 /*
  * decompressMany: decode n independent zlib (RFC 1950) streams, one wavefront per stream.
@@ -152,7 +159,7 @@ int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
  * context's device arenas (H2D, kernel, D2H) and returns when results are in host memory.
  * Return value: PZG_RC_* for the call as a whole; per-stream results are in status[].
  */
-int pzg_decompress_many(pzg_ctx *ctx,
+PZG_API int pzg_decompress_many(pzg_ctx *ctx,
                         const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len,
                         uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap,
                         uint64_t *out_len, int32_t *status, uint32_t *detail,
@@ -166,7 +173,7 @@ int pzg_decompress_many(pzg_ctx *ctx,
  * dictionary checks DICTID against the dictionary's Adler-32 (PZG_E_DICT) and decodes with the dictionary as the
  * history in front of its output; every other stream behaves as in pzg_decompress_many.  dict_* may be NULL.
  */
-int pzg_decompress_many_dict(pzg_ctx *ctx,
+PZG_API int pzg_decompress_many_dict(pzg_ctx *ctx,
                              const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len,
                              const uint8_t *dict_base, const uint64_t *dict_off, const uint64_t *dict_len,
                              uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap,
@@ -195,43 +202,43 @@ int pzg_decompress_many_dict(pzg_ctx *ctx,
  * Host pointers only.  Nothing is re-decoded: a feed costs what its new input costs.
  */
 typedef struct pzg_decoder pzg_decoder;
-int  pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out);  /* takes a reference on ctx */
-void pzg_decoder_destroy(pzg_decoder *dec);  /* legal before or after pzg_shutdown(ctx); NULL is ignored */
-int  pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m);  /* those decoders start a new stream */
-int  pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m,
+PZG_API int  pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out);  /* takes a reference on ctx */
+PZG_API void pzg_decoder_destroy(pzg_decoder *dec);  /* legal before or after pzg_shutdown(ctx); NULL is ignored */
+PZG_API int  pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m);  /* those decoders start a new stream */
+PZG_API int  pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m,
                       const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len, const uint8_t *final_in,
                       uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap,
                       uint64_t *out_len, int32_t *state, uint32_t *detail, uint64_t *in_used,
                       uint32_t *chunks, uint32_t *adler);
 
 /* decompress: the single-stream form (n = 1, host pointers). */
-int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len,
+PZG_API int pzg_decompress(pzg_ctx *ctx, const uint8_t *in, uint64_t in_len,
                    uint8_t *out, uint64_t out_cap, uint64_t *out_len,
                    int32_t *status, uint32_t detail[2], uint64_t *in_used);
 
 /* Adler-32 of one buffer (Codec.Compression.Zlib.Adler32, Adler32.hs:17-57) as a device-wide
  * reduction.  `init` is a finalized Adler value (1 for a fresh checksum). */
-int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init,
+PZG_API int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init,
                 uint32_t *out, uint32_t flags);
 
 /* The batched form (BASELINE config 2, 262,144 x 64 KiB): out[i] = Adler-32 of base[off[i] .. off[i]+len[i]), one wave per
  * buffer.  Device memory only (PZG_DEVICE_PTRS). */
-int pzg_adler32_many(pzg_ctx *ctx, const uint8_t *base, const uint64_t *off, const uint64_t *len,
+PZG_API int pzg_adler32_many(pzg_ctx *ctx, const uint8_t *base, const uint64_t *off, const uint64_t *len,
                      uint32_t *out, uint32_t n, uint32_t flags);
 
 /* Exact `show` text of the DecompressionError the reference returns for (status, detail) on
  * this stream (host memory; needed only for PZG_E_HUFF_BUILD, whose message depends on the
  * trie insertion order).  Writes a NUL-terminated string; returns its length. */
-int pzg_error_message(const uint8_t *in, uint64_t in_len, int32_t status,
+PZG_API int pzg_error_message(const uint8_t *in, uint64_t in_len, int32_t status,
                       const uint32_t detail[2], char *buf, size_t buf_len);
 
 /* Kernel time of the last launch on this context in milliseconds (HIP events on the launch
  * stream), or a negative value if none was recorded. */
-double pzg_last_kernel_ms(pzg_ctx *ctx);
+PZG_API double pzg_last_kernel_ms(pzg_ctx *ctx);
 
-const char *pzg_strerror(int rc);
-const char *pzg_last_error(pzg_ctx *ctx);
-uint32_t    pzg_version(void);
+PZG_API const char *pzg_strerror(int rc);
+PZG_API const char *pzg_last_error(pzg_ctx *ctx);
+PZG_API uint32_t    pzg_version(void);
 
 #ifdef __cplusplus
 }

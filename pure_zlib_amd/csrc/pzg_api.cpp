@@ -719,7 +719,7 @@ extern "C" {
 
 #if defined(PZG_PROFILE)
 // diagnostic builds only: device buffer of 16 uint64 per stream the kernel fills with cycle counters
-int pzg_prof_buffer(pzg_ctx *ctx, uint32_t n, uint64_t *host_out)
+PZG_API int pzg_prof_buffer(pzg_ctx *ctx, uint32_t n, uint64_t *host_out)
 {
     if (!ctx->prof_buf) { if (hipMalloc(&ctx->prof_buf, 128u * 1048576u) != hipSuccess) return -1; }
     if (host_out) return hipMemcpy(host_out, ctx->prof_buf, 128u * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;

@@ -16,22 +16,26 @@ namespace pzg {
 
 // ------------------------------------------------------------------------------------------------
 // inflate: a persistent grid of one-wave workgroups (block = 64 threads), each pulling stream indices
-// from a device counter.  LDS per workgroup = sizeof(WaveLds): 35.5 KiB at RING_BITS = 15 (four
-// stream-waves per CU, one per SIMD) down to 5.5 KiB at RING_BITS = 11 (28 per CU).
+// from a device counter.  LDS per workgroup = sizeof(WaveLds): 36 KiB at RING_BITS = 15 (four
+// stream-waves per CU, one per SIMD) down to 6 KiB at RING_BITS = 11 (26 per CU).
 // Waves per SIMD each instance is compiled for (its VGPR budget: 512 / waves, in steps of 8) and the
 // resident stream-waves per CU that follow from it and from sizeof(WaveLds) against the 160 KiB of LDS.
 #ifndef PZG_MIN_WAVES_11
 #define PZG_MIN_WAVES_11 7
 #endif
-constexpr int waves_per_simd(int ring_bits)
+// (there is no gzip instance of ring 11: it needs more vector registers than 7 or 6 waves per SIMD leave -- it spilled to
+// scratch -- and at 5 waves per SIMD it has the residency of ring 12, which reads less of its window from HBM: gzip
+// batches run the ring-12 instance, see launch_inflate)
+constexpr int waves_per_simd(int ring_bits, bool gzip = false)
 {
+    (void)gzip;
     return ring_bits <= 11 ? PZG_MIN_WAVES_11 : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
 }
-template <int RING_BITS>
+template <int RING_BITS, bool GZIP = false>
 constexpr uint32_t waves_per_cu()
 {
     constexpr uint32_t by_lds = (160u * 1024u) / (uint32_t)((sizeof(WaveLds<RING_BITS>) + 511u) / 512u * 512u);
-    constexpr uint32_t by_vgpr = 4u * (uint32_t)(RING_BITS >= 13 ? 4 : waves_per_simd(RING_BITS));  // rings 13-15 fit 128 VGPRs
+    constexpr uint32_t by_vgpr = 4u * (uint32_t)(RING_BITS >= 13 ? 4 : waves_per_simd(RING_BITS, GZIP));  // rings 13-15 fit 128 VGPRs
     return by_lds < by_vgpr ? by_lds : by_vgpr;
 }
 
@@ -49,7 +53,7 @@ __device__ __forceinline__ LaunchArgs launch_args()
 }
 
 template <int RING_BITS, bool FIXUP, bool GZIP = false>
-__global__ __launch_bounds__(64, waves_per_simd(RING_BITS)) void inflate_kernel(InflateArgs)
+__global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_kernel(InflateArgs)
 {
     __shared__ WaveLds<RING_BITS> lds;
     if (FIXUP && __builtin_nontemporal_load(launch_args()->counter + 1) == 0u) return;  // nothing was handed back
@@ -303,7 +307,8 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     if (a.n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back
     if (e != hipSuccess) return e;
-    // Resident stream-waves per CU: 4 / 8 / 13 / 20 / 28 for rings 15 .. 11 (LDS-bound except ring 11: 72 VGPRs, 7 per SIMD)
+    // Resident stream-waves per CU: 4 / 8 / 13 / 20 / 26 for rings 15 .. 11 (LDS-bound; ring 11: 72 VGPRs, 7 per SIMD by registers)
+    if (a.gzip && ring_bits == 11) ring_bits = 12;  // (no gzip instance of ring 11: see waves_per_simd)
     const uint32_t per_cu = ring_bits == 15 ? waves_per_cu<15>() : ring_bits == 14 ? waves_per_cu<14>()
                             : ring_bits == 13 ? waves_per_cu<13>() : ring_bits == 12 ? waves_per_cu<12>() : waves_per_cu<11>();
     uint32_t waves = (uint32_t)num_cus * per_cu;
@@ -329,7 +334,7 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     else if (ring_bits == 12)
         PZG_LAUNCH_RING(12);
     else if (ring_bits == 11)
-        PZG_LAUNCH_RING(11);
+        hipLaunchKernelGGL((inflate_kernel<11, false, false>), grid, block, 0, stream, a);
     else
         return hipErrorInvalidValue;
 #undef PZG_LAUNCH_RING

@@ -80,6 +80,10 @@ PZG_FN uint64_t ballot(bool p)
 PZG_FN uint32_t mbcnt(uint64_t m)
 {
 #if PZG_DEVICE_PASS
+    // (a mask known to be empty at compile time -- queue_append() for one half only -- counts nothing: the compiler does not
+    // fold the two instructions itself, it hoists their result to the kernel's prologue and keeps it in a register, or
+    // spills it: the one scratch slot of round 2's build)
+    if (__builtin_constant_p(m) && m == 0ull) return 0u;
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 #else
     (void)m;

@@ -28,6 +28,50 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_ffi.SYMBOLS) == decl
 
 
+def test_dynamic_symbol_table_is_exactly_the_abi():
+    """-fvisibility=hidden + csrc/pzg.map: libpzg.so exports the entry points of include/pzg.h and nothing else (no
+    launcher, kernel stub or std:: instantiation leaks into the process' symbol namespace)."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == declared_symbols()
+
+
+def _kernel_notes():
+    """{kernel name: {field: int}} from the gfx950 code object inside libpzg.so (its AMDGPU metadata note)."""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "co.elf")
+        subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, _ffi.LIB_PATH, os.path.join(d, "unused.so")])
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               "--input=" + fat, "--output=" + co])
+        notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co]).decode()
+    kernels = {}
+    for block in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", block, flags=re.M)}
+    return kernels
+
+
+def test_ring11_kernels_use_no_scratch():
+    """the shipped inflate_kernel<11,*,*> spilled a vector register to scratch (a VMEM round trip beside the
+    token queue's compaction, and scratch set-up for every wave).  Every small-ring instance -- the throughput path -- must
+    keep everything in registers; the scalar spill count (v_writelane / v_readlane pairs, none of them in the hot loop) is
+    kept under a budget so that it cannot creep up unnoticed."""
+    kernels = _kernel_notes()
+    ring11 = {n: k for n, k in kernels.items() if "inflate_kernelILi11E" in n}
+    assert len(ring11) == 1, sorted(kernels)  # (gzip batches run the ring-12 instance)
+    for name, k in kernels.items():
+        if "inflate_kernelILi1" in name:  # every ring size class, zlib and gzip, and the fixup instances
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
+    for name, k in ring11.items():
+        assert k["sgpr_spill_count"] <= 112, (name, k["sgpr_spill_count"])
+        assert k["vgpr_count"] <= 72, (name, k["vgpr_count"])  # 7 waves per SIMD by registers
+        assert k["group_segment_fixed_size"] <= 6144, name  # 26 stream-waves per CU
+
+
 def test_version_and_strerror():
     L = _ffi.lib()
     assert L.pzg_version() == 2  # (major << 16) | minor: 0.2
