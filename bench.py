@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
     ap.add_argument("--blob-bytes", type=int, default=32768)
     ap.add_argument("--level", type=int, default=6)
-    ap.add_argument("--pool", type=int, default=2048, help="distinct blobs; the batch replicates them at distinct addresses")
+    ap.add_argument("--pool", type=int, default=8192, help="distinct blobs (SURVEY.md 8d: P = 8192); the batch replicates them at distinct addresses")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="streams of the ONE-THREAD CPU baseline legs (rank 0, N=1); 0 = no CPU baseline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline legs (0 = every core)")
     ap.add_argument("--adler-gib", type=float, default=16.0, help="Adler-32 microbench size (BASELINE config 2); 0 = skip")
@@ -349,18 +349,41 @@ def main():
 
         import ctypes as C
         for fn in (L.pzo_decompress_many_mt, L.pzo_zlib_many_mt):  # oracle/pz_baseline_mt.c: POSIX threads over the batch layout
-            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.c_void_p]
             fn.restype = C.c_uint32
         u_off, u_len, u_cap = (np.ascontiguousarray(a, dtype=np.uint64) for a in (in_off, in_len, out_cap))
+        cpu_adler = np.zeros(n, dtype=np.uint32)  # the Adler-32 each CPU decoder computed over ITS output, per stream
 
         def timed(fn, count, threads):
             nb = C.c_uint64(0)
+            cpu_adler[:] = 0
             t0 = time.perf_counter()
-            bad = fn(h_in.ctypes.data, u_off.ctypes.data, u_len.ctypes.data, u_cap.ctypes.data, count, threads, C.byref(nb))
+            bad = fn(h_in.ctypes.data, u_off.ctypes.data, u_len.ctypes.data, u_cap.ctypes.data, count, threads, C.byref(nb),
+                     cpu_adler.ctypes.data)
             dt = time.perf_counter() - t0
             if bad:
                 raise SystemExit(f"the CPU baseline rejected {bad} bench stream(s)")
             return int(nb.value), dt
+
+        def cpu_quota():
+            """What the box grants this process: cgroup CPU quota (cores' worth of time) and the affinity mask's size."""
+            q = None
+            try:
+                with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+                    a, b = f.read().split()
+                    q = None if a == "max" else round(int(a) / int(b), 2)
+            except Exception:
+                try:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        a, b = int(f.read()), int(g.read())
+                        q = None if a < 0 else round(a / b, 2)
+                except Exception:
+                    pass
+            try:
+                aff = len(os.sched_getaffinity(0))
+            except Exception:
+                aff = None
+            return q, aff
 
         m1 = min(args.cpu_sample, n)
         nb_o1, dt_o1 = timed(L.pzo_decompress_many_mt, m1, 1)
@@ -368,12 +391,17 @@ def main():
         # all cores: the box may hand this process less than its logical CPU count (quota), so a few thread counts are
         # tried on the whole batch and the best one is what is reported, with its thread count
         best = None
+        gpu_vs_port = not args.no_verify and not args.gzip
         for th in sorted({nthreads, max(1, nthreads // 2), max(1, nthreads // 4), min(nthreads, 32), min(nthreads, 16)}, reverse=True):
             nb_o, dt_o = timed(L.pzo_decompress_many_mt, n, th)
+            # GPU output against the restatement on EVERY stream of the timed batch -- the oracle's per-stream
+            # Adler-32 (computed over the bytes the oracle itself produced) against the adler[] the kernel returned
+            gpu_vs_port = gpu_vs_port and nb_o == int(out_cap.sum()) and bool((cpu_adler == adler).all())
             if best is None or nb_o / dt_o > best[0] / best[1]:
                 best = (nb_o, dt_o, th)
         nb_oa, dt_oa, nthreads = best
         nb_za, dt_za = timed(L.pzo_zlib_many_mt, n, nthreads)
+        quota, affinity = cpu_quota()
         model = ""
         try:
             with open("/proc/cpuinfo") as f:
@@ -391,8 +419,15 @@ def main():
             "one_thread_sample": f"first {m1} streams ({nb_o1 / 2**20:.0f} MiB), {dt_o1:.1f}s",
             "system_zlib_all_cores_GiBps": round(nb_za / dt_za / 2**30, 2),
             "system_zlib_one_thread_GiBps": round(nb_z1 / dt_z1 / 2**30, 3),
+            "gpu_equals_port_on_every_stream": gpu_vs_port,
+            "gpu_vs_port_check": f"per-stream Adler-32 + length of all {n} streams of the timed batch: the oracle's own checksum over its "
+                                 "own output vs the kernel's adler[] (beside the full byte compare with the plaintext above)",
             "host": model,
             "host_cores_available": cores,
+            "cgroup_cpu_quota_cores": quota,
+            "sched_affinity_cpus": affinity,
+            "cores_note": "cores = the thread count with the best all-core rate among {all, 1/2, 1/4, 32, 16}; the box's cgroup quota / "
+                          "affinity (above; null = unlimited) is what keeps it below host_cores_available",
             "note": "the Haskell reference itself cannot run here (no GHC); README.md:6-8 of the reference puts it ~100x below C zlib. "
                     "system zlib = libz's uncompress() on the same batch and threads (oracle/pz_baseline_mt.c).",
         }
@@ -402,13 +437,16 @@ def main():
         nb = int(args.adler_gib * 2**30)
         free, _tot = torch.cuda.mem_get_info()
         nb = min(nb, int(free * 0.8))
+        nb &= ~7
         buf = torch.empty(nb, dtype=torch.uint8, device=dev)
-        g = torch.Generator(device=dev)
-        g.manual_seed(0x5EED0002)
         chunk = 1 << 28
-        for lo in range(0, nb, chunk):
-            hi = min(nb, lo + chunk)
-            buf[lo:hi] = torch.randint(0, 256, (hi - lo,), dtype=torch.uint8, device=dev, generator=g)
+        # byte i = byte (i & 7) of splitmix64(0x5EED0002 + (i >> 3)), little-endian; filled on the device
+        words = buf.view(torch.int64)
+        for lo in range(0, nb // 8, chunk // 8):
+            hi = min(nb // 8, lo + chunk // 8)
+            words[lo:hi] = corpus.splitmix64_torch(lo, hi - lo, dev)
+        gen_ok = all(np.array_equal(buf[lo:lo + 4096].cpu().numpy(), corpus.splitmix64_numpy(lo // 8, 512).view(np.uint8))
+                     for lo in (0, (nb // 2) & ~7, nb - 4096))  # the CPU generator, same definition, at three places
         d_res = torch.zeros(1, dtype=torch.int32, device=dev)
         for _ in range(2):
             ctx.adler32_device(buf.data_ptr(), nb, d_res.data_ptr(), sync=True)
@@ -428,6 +466,7 @@ def main():
             "frac_of_measured_copy_6290": round(nb / (med * 1e-3) / 1e9 / HBM_MEASURED_GBS, 4),
             "kernel_ms_median": round(med, 3),
             "matches_zlib_adler32": bool(got == exp),
+            "buffer": "splitmix64(0x5EED0002 + (i >> 3)) bytes, little-endian (SURVEY.md 8d); device fill == CPU generator: " + str(gen_ok),
         }
         # ... and its batched form: 64 KiB buffers, one wave each, pzg_adler32_many
         nbuf = nb // 65536

@@ -16,6 +16,7 @@ module Codec.Compression.Zlib
   , ZlibDecoder (NeedMore, Chunk, Done, DecompError)
   , decompress
   , decompressMany
+  , decompressManyStrict
   , decompressIncremental
   ) where
 
@@ -30,7 +31,7 @@ import qualified Data.ByteString.Lazy as L
 import qualified Data.ByteString.Unsafe as SU
 import Data.IORef (IORef, newIORef, readIORef, writeIORef)
 import Data.Int (Int32)
-import Data.List (isPrefixOf)
+import Data.List (isPrefixOf, zip4)
 import Data.Word (Word32, Word64, Word8)
 import Foreign
   ( FinalizerPtr, ForeignPtr, Ptr, alloca, allocaArray, allocaBytes, castPtr, copyBytes
@@ -150,21 +151,44 @@ decompressMany :: [L.ByteString] -> [Either DecompressionError L.ByteString]
 decompressMany inputs = unsafePerformIO $ do
   let chunked = map (filter (not . S.null) . L.toChunks) inputs
       flats = map S.concat chunked
-      caps0 = map (\b -> max 256 (4 * S.length b)) flats
-  first <- launch flats caps0
-  -- second pass: only the streams whose capacity was too small
-  let need = [ (i, fromIntegral len) | (i, (st, len, _, _, _)) <- zip [0 :: Int ..] first, st == stOutTooSmall ]
-  second <- if null need then return [] else launch [ flats !! i | (i, _) <- need ] (map snd need)
-  let redo = zip (map fst need) second
-      pick i r = maybe r id (lookup i redo)
-  forM (zip3 [0 ..] chunked flats) $ \(i, chunks, flat) -> do
-    let (st, _len, used, out, det) = pick i (first !! i)
+  results <- decodeBatch flats
+  forM (zip3 chunked flats results) $ \(chunks, flat, (st, _len, used, out, det)) ->
     if st == stOk
       then return (chunkRule chunks used (L.fromStrict out))
-      else Left <$> (allocaArray 2 $ \pdet -> pokeArray pdet [fst det, snd det] >> errorFor flat st pdet)
+      else Left <$> errorOf flat st det
+
+-- | The strict form (SURVEY.md 8b): one strict 'S.ByteString' per stream in, one out -- no lazy-chunk
+-- bookkeeping and no list indexing anywhere on the way (a strict input is ONE chunk, so Zlib.hs:46-49's
+-- "Finished with data remaining." can never fire: trailing bytes inside the chunk are ignored, as there).
+decompressManyStrict :: [S.ByteString] -> [Either DecompressionError S.ByteString]
+decompressManyStrict inputs = unsafePerformIO $ do
+  results <- decodeBatch inputs
+  forM (zip inputs results) $ \(flat, (st, _len, _used, out, det)) ->
+    if st == stOk then return (Right out) else Left <$> errorOf flat st det
+
+errorOf :: S.ByteString -> Int32 -> (Word32, Word32) -> IO DecompressionError
+errorOf flat st det = allocaArray 2 $ \pdet -> pokeArray pdet [fst det, snd det] >> errorFor flat st pdet
+
+type StreamResult = (Int32, Word64, Word64, S.ByteString, (Word32, Word32))  -- status, out_len, in_used, bytes, detail
+
+-- | Both passes over a batch of flat streams, results in input order: the first launch with a capacity
+-- guess per stream, the second for the streams whose guess was too small, with their exact sizes.
+decodeBatch :: [S.ByteString] -> IO [StreamResult]
+decodeBatch flats = do
+  first <- launch flats (map (\b -> max 256 (4 * S.length b)) flats)
+  let need = [ (flat, fromIntegral len) | (flat, (st, len, _, _, _)) <- zip flats first, st == stOutTooSmall ]
+  second <- if null need then return [] else launch (map fst need) (map snd need)
+  return (merge first second)
+ where
+  -- the second pass' results take the places of the too-small ones, in order (no indexing: both lists are walked once)
+  merge (r@(st, _, _, _, _) : rs) redo@(r2 : redo')
+    | st == stOutTooSmall = r2 : merge rs redo'
+    | otherwise = r : merge rs redo
+  merge rs [] = rs
+  merge [] _ = []
 
 -- | One pzg_decompress_many call on host buffers.  Per stream: (status, out_len, in_used, bytes, detail).
-launch :: [S.ByteString] -> [Int] -> IO [(Int32, Word64, Word64, S.ByteString, (Word32, Word32))]
+launch :: [S.ByteString] -> [Int] -> IO [StreamResult]
 launch flats caps = do
   let n = length flats
       align16 x = (x + 15) .&. complement 15
@@ -188,11 +212,13 @@ launch flats caps = do
       lens <- peekArray n polen
       useds <- peekArray n pused
       dets <- peekArray (2 * n) pdet
-      forM (zip [0 ..] (zip3 sts lens useds)) $ \(i, (st, len, used)) -> do
-        let cap = caps !! i
-            nb = if st == stOk then fromIntegral len else 0 :: Int
-        out <- SI.create (min nb cap) $ \d -> copyBytes d (pout `plusPtr` (ooffs !! i)) (min nb cap)
-        return (st, len, used, out, (dets !! (2 * i), dets !! (2 * i + 1)))
+      forM (zip4 caps ooffs (pairs dets) (zip3 sts lens useds)) $ \(cap, ooff, det, (st, len, used)) -> do
+        let nb = if st == stOk then fromIntegral len else 0 :: Int
+        out <- SI.create (min nb cap) $ \d -> copyBytes d (pout `plusPtr` ooff) (min nb cap)
+        return (st, len, used, out, det)
+ where
+  pairs (a : b : rest) = (a, b) : pairs rest
+  pairs _ = []
 
 -- ---------------------------------------------------------------------------------------------
 -- decompressIncremental (Zlib.hs:29-30) and the ZlibDecoder protocol (Monad.hs:163-197): the

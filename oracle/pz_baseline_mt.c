@@ -5,6 +5,9 @@
  *   pzo_decompress_many_mt   the oracle (oracle/pz_oracle.c: the bit-at-a-time restatement of pure-zlib)
  *   pzo_zlib_many_mt         system zlib's uncompress() (libz 1.2.11), the specification-equal C decoder
  * Both return the number of streams that failed or whose length differs from out_cap[i]; *bytes gets the total decoded.
+ * adler_out (may be NULL): per stream, the Adler-32 of the bytes THIS decoder produced (the oracle's own running checksum,
+ * Adler32.hs:17-57; for zlib, adler32() over its output) -- bench.py compares it with the GPU's adler[] for every stream
+ * of the timed batch (GPU vs restatement on every stream, not a sample).
  */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
@@ -19,6 +22,7 @@ typedef struct {
     const uint8_t *in_base;
     const uint64_t *in_off, *in_len, *out_cap;
     uint32_t n;
+    uint32_t *adler_out;
     int use_zlib;
     atomic_uint next;
     atomic_ullong bytes;
@@ -43,13 +47,19 @@ static void *worker(void *arg)
             }
             if (j->use_zlib) {
                 uLongf dl = (uLongf)cap;
-                if (uncompress(out, &dl, j->in_base + j->in_off[i], (uLong)j->in_len[i]) != Z_OK || dl != j->out_cap[i]) bad++;
-                else bytes += dl;
+                if (uncompress(out, &dl, j->in_base + j->in_off[i], (uLong)j->in_len[i]) != Z_OK || dl != j->out_cap[i]) {
+                    bad++;
+                    if (j->adler_out) j->adler_out[i] = 0u;
+                } else {
+                    bytes += dl;
+                    if (j->adler_out) j->adler_out[i] = (uint32_t)adler32(1L, out, (uInt)dl);
+                }
             } else {
                 pzo_result r;
                 pzo_decompress(j->in_base + j->in_off[i], j->in_len[i], out, j->out_cap[i], &r);
                 if (r.status != PZO_OK || r.out_len != j->out_cap[i]) bad++;
                 else bytes += r.out_len;
+                if (j->adler_out) j->adler_out[i] = r.adler;
             }
         }
     }
@@ -60,7 +70,7 @@ static void *worker(void *arg)
 }
 
 static uint32_t run(const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len, const uint64_t *out_cap, uint32_t n,
-                    uint32_t nthreads, int use_zlib, uint64_t *bytes)
+                    uint32_t nthreads, int use_zlib, uint64_t *bytes, uint32_t *adler_out)
 {
     job_t j;
     pthread_t *th;
@@ -70,6 +80,7 @@ static uint32_t run(const uint8_t *in_base, const uint64_t *in_off, const uint64
     j.in_len = in_len;
     j.out_cap = out_cap;
     j.n = n;
+    j.adler_out = adler_out;
     j.use_zlib = use_zlib;
     atomic_init(&j.next, 0u);
     atomic_init(&j.bytes, 0ull);
@@ -86,13 +97,13 @@ static uint32_t run(const uint8_t *in_base, const uint64_t *in_off, const uint64
 }
 
 uint32_t pzo_decompress_many_mt(const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len, const uint64_t *out_cap,
-                                uint32_t n, uint32_t nthreads, uint64_t *bytes)
+                                uint32_t n, uint32_t nthreads, uint64_t *bytes, uint32_t *adler_out)
 {
-    return run(in_base, in_off, in_len, out_cap, n, nthreads, 0, bytes);
+    return run(in_base, in_off, in_len, out_cap, n, nthreads, 0, bytes, adler_out);
 }
 
 uint32_t pzo_zlib_many_mt(const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len, const uint64_t *out_cap, uint32_t n,
-                          uint32_t nthreads, uint64_t *bytes)
+                          uint32_t nthreads, uint64_t *bytes, uint32_t *adler_out)
 {
-    return run(in_base, in_off, in_len, out_cap, n, nthreads, 1, bytes);
+    return run(in_base, in_off, in_len, out_cap, n, nthreads, 1, bytes, adler_out);
 }

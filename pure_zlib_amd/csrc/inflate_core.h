@@ -296,7 +296,6 @@ struct BitReader {
     uint32_t chunk0;       // dword index of the 64-dword chunk the cursor is in (a multiple of 64; lane 0 of `cur`)
     uint32_t rp;           // next unread bit, relative to bit 32 * chunk0; slide() keeps it below 2048
     int32_t rp_ok1, rp_ok2;  // rp below these (signed): a 64-bit / a 128-bit window may run (set_limits)
-    int32_t rp_fast;         // rp below this: a 128-bit window may run AND all its dwords are in `cur` (hot_loop's one test)
 #if PZG_DEVICE_PASS
     uint32_t cur, nxt;     // per-lane: dwords chunk0 + lane and chunk0 + 64 + lane
 #if PZG_DMA_PREFETCH
@@ -349,11 +348,7 @@ struct BitReader {
         d = d > 4096u ? 4096u : d;  // (rp stays below 2048 + one window: anything past that is "yes")
         rp_ok1 = (int32_t)uni(d * 32u);  // (pinned to scalar registers: the hot loop compares against them once per window)
         rp_ok2 = (int32_t)uni(d * 32u - 96u);
-        rp_fast = (int32_t)uni((uint32_t)(rp_ok2 < (int32_t)WIN2_CUR_ONLY ? rp_ok2 : (int32_t)WIN2_CUR_ONLY));
     }
-    // a 128-bit window at rp reads dwords (rp >> 5) .. (rp >> 5) + 7 of the chunk (five gathers by lanes at up to 63 + 96 bits
-    // further on): below this they all lie in `cur`
-    static constexpr uint32_t WIN2_CUR_ONLY = 57u * 32u;
 
     PZG_FN void start(const uint8_t *in, uint64_t in_len, uint64_t byte_pos)
     {
@@ -499,7 +494,6 @@ struct Decoder {
         br.rp = uni(br.rp);
         br.rp_ok1 = (int32_t)uni((uint32_t)br.rp_ok1);
         br.rp_ok2 = (int32_t)uni((uint32_t)br.rp_ok2);
-        br.rp_fast = (int32_t)uni((uint32_t)br.rp_fast);
         br.chunk0 = uni(br.chunk0);
         br.end_rel = uni64(br.end_rel);
         br.ndw = uni(br.ndw);
@@ -1317,16 +1311,15 @@ struct Decoder {
         spec_dist<FX>(t);
         spec_finish(t, tb, tk);
     }
-    // two independent decodes, stage by stage.  SUBMODE: 0 the block's use_sub decides at run time, 1 no second-level
-    // lookup, 2 always (hot_loop is instantiated for both, so that its windows do not test use_sub)
-    template <bool FX, int SUBMODE = 0>
+    // two independent decodes, stage by stage
+    template <bool FX>
     PZG_FN void decode_pair(uint32_t lo0, uint32_t mid0, uint32_t hi0, uint32_t mid1, uint32_t hi1, uint32_t r, uint32_t &tb0,
                             uint32_t &tk0, uint32_t &tb1, uint32_t &tk1)
     {
         Spec a, b;
         spec_bits<FX>(a, lo0, mid0, hi0, r);
         spec_bits<FX>(b, hi0, mid1, hi1, r);
-        if (!FX && SUBMODE != 1 && (SUBMODE == 2 || use_sub)) {  // wave-uniform
+        if (!FX && use_sub) {  // wave-uniform
             uint32_t ea = spec_sub_load(a), eb = spec_sub_load(b);  // (both lookups in flight together)
 #if PZG_DEVICE_PASS
             asm("" : "+v"(ea), "+v"(eb));
@@ -1466,72 +1459,49 @@ struct Decoder {
     // decoded from stream bits alone (a prefix code is settled by its own bits, whatever follows them); any other is made
     // a stopper, so the walk ends in front of it and token_step_checked() finds what the reference finds there
     // (the end-of-block code as a rule; a truncated stream otherwise).
-    // The stream bits of a window, as the lanes see them: lane k's first token starts at bit p = rp + k of the chunk: dword
-    // d = p >> 5 (the window's dwords sit in `cur`, or in `cur` and `nxt`), bit r = p & 31 of it.  The crossbar takes a byte
-    // address and ignores its low two bits (lane = address[7:2]) and the funnel shift its amount's high bits, so p >> 3 and
-    // p themselves will do.  (Device only: the one-lane host model reads its dwords in window2_finish().)
-    struct Win2 {
-        uint32_t lo0, mid0, hi0, mid1, hi1, r;
-    };
-    PZG_FN void window2_gather(Win2 &w)  // the five dwords from `cur`
-    {
-#if PZG_DEVICE_PASS
-        const uint32_t r = br.rp + lane_id(), a = r >> 3;
-        w.r = r;
-        w.lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
-        w.mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
-        w.hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
-        w.mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
-        w.hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
-#else
-        (void)w;
-#endif
-    }
-    PZG_FN void window2_gather_nxt(Win2 &w)  // (one window in nine) the dwords past `cur`: the same gathers from the next chunk
-    {
-#if PZG_DEVICE_PASS
-        const uint32_t d = w.r >> 5;
-        const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.nxt);
-        const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.nxt);
-        const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.nxt);
-        const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 3u) << 2), (int)br.nxt);
-        const uint32_t n4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 4u) << 2), (int)br.nxt);
-        w.lo0 = d >= 64u ? n0 : w.lo0;  // (the crossbar index wraps modulo 64, so dword d of `nxt` is lane d - 64)
-        w.mid0 = d + 1u >= 64u ? n1 : w.mid0;
-        w.hi0 = d + 2u >= 64u ? n2 : w.hi0;
-        w.mid1 = d + 3u >= 64u ? n3 : w.mid1;
-        w.hi1 = d + 4u >= 64u ? n4 : w.hi1;
-#else
-        (void)w;
-#endif
-    }
-    // the 128 speculative decodes: lane k's tokens at bit offsets k (TB0, TK0) and k + 64 (TB1, TK1)
-    template <bool FX, int SUBMODE>
-    PZG_FN void window2_finish(const Win2 &w, LaneVec<uint32_t> &TB0, LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TB1, LaneVec<uint32_t> &TK1)
-    {
-#if PZG_DEVICE_PASS
-        decode_pair<FX, SUBMODE>(w.lo0, w.mid0, w.hi0, w.mid1, w.hi1, w.r, TB0.v, TK0.v, TB1.v, TK1.v);
-#else
-        (void)w;
-        const uint32_t i0 = br.chunk0 + (br.rp >> 5), boff = br.rp & 31u;
-        PZG_LANES_BEGIN(k)
-            const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
-            decode_pair<FX, SUBMODE>(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
-                                     PZG_LV(TB0, k), PZG_LV(TK0, k), PZG_LV(TB1, k), PZG_LV(TK1, k));
-        PZG_LANES_END
-#endif
-#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
-        prof[6] += 2;
-#endif
-    }
     template <bool FX, bool TAIL = false>
     PZG_FN void window2_decode(LaneVec<uint32_t> &TB0, LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TB1, LaneVec<uint32_t> &TK1)
     {
         PZG_MARK("w2.begin");
-        Win2 w;
-        window2_gather(w);
-        if (__builtin_expect(br.rp >= BitReader::WIN2_CUR_ONLY, 0)) window2_gather_nxt(w);
-        window2_finish<FX, 0>(w, TB0, TK0, TB1, TK1);
+#if PZG_DEVICE_PASS
+        {
+            // lane k's first token starts at bit p = rp + k of the chunk: dword d = p >> 5 (the window's dwords sit in `cur`,
+            // or in `cur` and `nxt`), bit r = p & 31 of it.  The crossbar takes a byte address and ignores its low two bits
+            // (lane = address[7:2]) and the funnel shift its amount's high bits, so p >> 3 and p themselves will do.
+            const uint32_t li = br.rp >> 5;
+            const uint32_t r = br.rp + lane_id(), a = r >> 3, d = r >> 5;
+            uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
+            uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
+            uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
+            uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
+            uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
+            if (__builtin_expect(li > 56u, 0)) {  // (one window in nine) the same gathers from the next chunk for the dwords past this one
+                const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.nxt);
+                const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.nxt);
+                const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.nxt);
+                const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 3u) << 2), (int)br.nxt);
+                const uint32_t n4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 4u) << 2), (int)br.nxt);
+                lo0 = d >= 64u ? n0 : lo0;  // (the crossbar index wraps modulo 64, so dword d of `nxt` is lane d - 64)
+                mid0 = d + 1u >= 64u ? n1 : mid0;
+                hi0 = d + 2u >= 64u ? n2 : hi0;
+                mid1 = d + 3u >= 64u ? n3 : mid1;
+                hi1 = d + 4u >= 64u ? n4 : hi1;
+            }
+            decode_pair<FX>(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
+        }
+#else
+        {
+            const uint32_t i0 = br.chunk0 + (br.rp >> 5), boff = br.rp & 31u;
+            PZG_LANES_BEGIN(k)
+                const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
+                decode_pair<FX>(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
+                            PZG_LV(TB0, k), PZG_LV(TK0, k), PZG_LV(TB1, k), PZG_LV(TK1, k));
+            PZG_LANES_END
+        }
+#endif
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+        prof[6] += 2;
+#endif
         if (TAIL) {
             const int64_t av = br.avail();
             const uint32_t left = av < 0 ? 0u : av > 1024 ? 1024u : (uint32_t)av;  // stream bits from the cursor on
@@ -1868,80 +1838,60 @@ struct Decoder {
     // stays a region of plain scalar branches.  HL_WINDOW: the window decoded last (TK0, TK1, S0, S1, k0, k1) is one for
     // window2_rare(); HL_GENERAL: the general token loop has to take a step (stream tail, flush, copy_match).
     enum : uint32_t { HL_GENERAL = 1, HL_WINDOW = 2 };
-    // Round 3: ONE compare per window for the cursor (rp_fast: enough stream ahead and every dword of the window in `cur`;
-    // the chunk step, the stream's tail and the window that reaches into `nxt` all hide behind it) and ONE for the queue
-    // (what the window adds either keeps it short of QHIGH -- the next window follows at once -- or starts the segments;
-    // overflow is looked at only then); the block's use_sub is a template argument.  Every way out is a `break` to the ONE
-    // block behind the loop (several exit blocks, and the compiler funnels them through a dispatch variable that every
-    // iteration sets and tests).  The reason for leaving is not a variable of the loop (its constants would be moved into
-    // registers on the way of the windows that stay): it is read off S0 behind the loop -- a window that is handed to
-    // window2_rare() has visited offset 0, the other two exits clear S0.
-    template <bool FX, int SUBMODE>
+    template <bool FX>
     PZG_FN uint32_t hot_loop(LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TK1, uint64_t &S0, uint64_t &S1, uint32_t &k0, uint32_t &k1)
     {
-        S0 = 0;
-        if (qn < QHIGH) {  // (else: the general loop emits a segment first)
+        uint32_t why;
 #if PZG_DEVICE_PASS && PZG_HOT_ALIGN
         // the loop starts on a fixed boundary, so that where its blocks fall within the instruction-fetch blocks does not
         // move with every edit of the code in front of it (measured neutral at 0 / 64 / 128 / 256 bytes on this build)
         asm volatile(".p2align " PZG_STR(PZG_HOT_ALIGN));
 #endif
         for (;;) {
-            Win2 w;
-            window2_gather(w);
-            if (__builtin_expect((int32_t)br.rp >= (int32_t)uni((uint32_t)br.rp_fast), 0)) {  // (uni: keeps the compare, and with it the loop, scalar)
-                if (br.rp >= 2048u) {  // the cursor has left the chunk (the windows only add to rp; less than 256 at a time)
-                    br.step_chunk();
-                    window2_gather(w);
+            if (qn < QHIGH) {
+                if (__builtin_expect(!br.window2_ok(), 0)) {
+                    why = HL_GENERAL;
+                    break;
                 }
-                if ((int32_t)br.rp >= (int32_t)uni((uint32_t)br.rp_fast)) {  // (again: the step has moved both)
-                    if (!br.window2_ok()) {
-                        S0 = 0;
-                        break;
-                    }
-                    window2_gather_nxt(w);  // (here rp >= WIN2_CUR_ONLY)
-                }
-            }
-            LaneVec<uint32_t> TB0, TB1;
-            window2_finish<FX, SUBMODE>(w, TB0, TK0, TB1, TK1);
+                LaneVec<uint32_t> TB0, TB1;
+                window2_decode<FX>(TB0, TK0, TB1, TK1);
 #if PZG_DEVICE_PASS && defined(PZG_EXP_NOP)   // cost-model experiments (never in the product build): per window,
-            asm volatile(".rept " PZG_STR(PZG_EXP_NOP) "\n\ts_nop 0\n\t.endr");                 // 4-byte no-ops
+                asm volatile(".rept " PZG_STR(PZG_EXP_NOP) "\n\ts_nop 0\n\t.endr");                 // 4-byte no-ops
 #endif
 #if PZG_DEVICE_PASS && defined(PZG_EXP_VALU4)
-            { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU4) "\n\tv_mov_b32_e32 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 4-byte vector
+                { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU4) "\n\tv_mov_b32_e32 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 4-byte vector
 #endif
 #if PZG_DEVICE_PASS && defined(PZG_EXP_VALU8)
-            { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU8) "\n\tv_mov_b32_e64 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 8-byte vector
+                { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU8) "\n\tv_mov_b32_e64 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 8-byte vector
+#endif
+#if PZG_DEVICE_PASS && defined(PZG_EXP_VALU_IND)   // ... independent of one another (four destinations, one source)
+                { uint32_t x = TB0.v, t0, t1, t2, t3; asm volatile(".rept " PZG_STR(PZG_EXP_VALU_IND) "\n\tv_mov_b32_e32 %0, %4\n\tv_mov_b32_e32 %1, %4\n\tv_mov_b32_e32 %2, %4\n\tv_mov_b32_e32 %3, %4\n\t.endr" : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(x)); }
+#endif
+#if PZG_DEVICE_PASS && defined(PZG_EXP_SALU_IND)
+                { uint32_t x = qn, t0, t1, t2, t3; asm volatile(".rept " PZG_STR(PZG_EXP_SALU_IND) "\n\ts_mov_b32 %0, %4\n\ts_mov_b32 %1, %4\n\ts_mov_b32 %2, %4\n\ts_mov_b32 %3, %4\n\t.endr" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(x)); }
 #endif
 #if PZG_DEVICE_PASS && defined(PZG_EXP_SALU4)
-            { uint32_t x = qn; asm volatile(".rept " PZG_STR(PZG_EXP_SALU4) "\n\ts_mov_b32 %0, %0\n\t.endr" : "+s"(x)); qn = x; }  // 4-byte scalar
+                { uint32_t x = qn; asm volatile(".rept " PZG_STR(PZG_EXP_SALU4) "\n\ts_mov_b32 %0, %0\n\t.endr" : "+s"(x)); qn = x; }  // 4-byte scalar
 #endif
-            S0 = 0;
-            S1 = 0;
-            k1 = 0;
-            k0 = walk_half(TB0, 0u, S0);
-            if (__builtin_expect(k0 >= 64u, 0)) break;
-            k1 = walk_half(TB1, k0, S1);
-            if (__builtin_expect(k1 >= 64u, 0)) break;
-            const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
-            const uint32_t qnn = (qn + nt0) + nt1;
-            if (qnn >= QHIGH) {  // the segments' turn
-                if (__builtin_expect(qnn > QCAP, 0)) break;
+                S0 = 0;
+                S1 = 0;
+                k1 = 0;
+                k0 = walk_half(TB0, 0u, S0);
+                why = HL_WINDOW;
+                if (__builtin_expect(k0 >= 64u, 0)) break;
+                k1 = walk_half(TB1, k0, S1);
+                if (__builtin_expect(k1 >= 64u, 0)) break;
+                const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
+                if (__builtin_expect((qn + nt0) + nt1 > QCAP, 0)) break;
                 queue_append(TK0, S0, nt0, TK1, S1, nt1);
-                br.rp += k1 + 128u;
-                S0 = 0;  // (should the segment leave the loop: no window to hand over)
-                // ONE segment, then windows again (no inner loop: its second way out would bring back a dispatch variable that
-                // every iteration tests).  A short segment can leave the queue at QHIGH or more: the next window then
-                // either still fits (and is followed by the next segment) or leaves through the overflow exit.
-                if (__builtin_expect(emit_body<true>() != ST_OK, 0)) break;
-            } else {  // the queue stays short: the next window
-                queue_append(TK0, S0, nt0, TK1, S1, nt1);
-                br.rp += k1 + 128u;
+                br.drop_short(k1 + 128u);
+                continue;
+            }
+            if (emit_body<true>() != ST_OK) {
+                why = HL_GENERAL;
+                break;
             }
         }
-        if (br.rp >= 2048u) br.step_chunk();  // (at most one)
-        }
-        uint32_t why = S0 != 0ull ? (uint32_t)HL_WINDOW : (uint32_t)HL_GENERAL;
 #if PZG_DEVICE_PASS
         asm volatile("" : "+s"(why));
 #endif
@@ -1958,8 +1908,7 @@ struct Decoder {
             LaneVec<uint32_t> TK0, TK1;
             uint64_t S0 = 0, S1 = 0;
             uint32_t k0 = 0, k1 = 0;
-            if (!RES) why = FX ? hot_loop<FX, 1>(TK0, TK1, S0, S1, k0, k1)
-                           : use_sub ? hot_loop<false, 2>(TK0, TK1, S0, S1, k0, k1) : hot_loop<false, 1>(TK0, TK1, S0, S1, k0, k1);
+            if (!RES) why = hot_loop<FX>(TK0, TK1, S0, S1, k0, k1);
             if (why == HL_WINDOW) checked = window2_rare(TK0, TK1, S0, S1, k0, k1);
             else checked = qn < QHIGH && fill_queue<FX>();
             PZG_ACC(4, tw);

@@ -3,6 +3,12 @@
 SURVEY.md section 8f row 2 ("next" row).  Same messages as the reference; the file is read in the chunk
 size `L.readFile` uses (bytestring's defaultChunkSize = 32 KiB minus two words) and driven through
 the ZlibDecoder protocol exactly like `runDecompression` (Deflate.hs:30-48).
+
+Batch mode (on top of the reference):  deflate a.z b.z c.z ...  decodes every file in ONE
+`decompressMany` call -- one wavefront per file, one launch -- and writes a, b, c.  Each file is handed over as the lazy
+ByteString `L.readFile` would make of it, so `decompress`'s own outcomes apply per file: "ERROR: <show e>" for a Left
+(including Zlib.hs:48-49's "Finished with data remaining."), "Unexpected file name." for a name that does not end in
+".z"; the other files are still decoded.
 """
 import sys
 
@@ -31,8 +37,36 @@ def run_decompression(out, chunks, decoder) -> None:
             decoder = decoder.next()
 
 
+def _lazy_chunks(data: bytes):
+    return [data[i:i + LAZY_CHUNK] for i in range(0, len(data), LAZY_CHUNK)]
+
+
+def run_many(files) -> None:
+    """Batch mode: every `.z` file of `files` through one decompress_many call."""
+    from .zlib import decompress_many
+    good = []
+    for f in files:
+        if f.endswith(".z"):
+            good.append(f)
+        else:
+            print(f"{f}: Unexpected file name.")
+    streams = []
+    for f in good:
+        with open(f, "rb") as h:
+            streams.append(_lazy_chunks(h.read()))
+    for f, r in zip(good, decompress_many(streams)):
+        if r.is_right():
+            with open(f[:-2], "wb") as out:
+                out.write(r.value)
+        else:
+            print(f"{f}: ERROR: " + r.value.show())
+
+
 def main(argv=None) -> int:
     args = sys.argv[1:] if argv is None else argv
+    if len(args) > 1:
+        run_many(args)
+        return 0
     if len(args) != 1:
         print("USAGE: deflate [filename]")
         return 0
@@ -42,7 +76,7 @@ def main(argv=None) -> int:
         return 0
     with open(ifile, "rb") as f:
         data = f.read()
-    chunks = [data[i:i + LAZY_CHUNK] for i in range(0, len(data), LAZY_CHUNK)]
+    chunks = _lazy_chunks(data)
     with open(ifile[:-2], "wb") as out:
         run_decompression(out, chunks, decompress_incremental())
     return 0

@@ -154,3 +154,30 @@ def gzip_member(data: bytes, seed: int) -> bytes:
     if flg & 2:
         hdr += struct.pack("<H", zlib.crc32(bytes(hdr)) & 0xffff)
     return bytes(hdr) + body + struct.pack("<II", zlib.crc32(data), len(data) & 0xffffffff)
+
+
+# ---- BASELINE config 2's buffer: byte i = byte (i & 7), little-endian, of splitmix64(seed + (i >> 3)) -----------
+SPLITMIX_SEED = 0x5EED0002
+
+
+def splitmix64_numpy(first, count):
+    """splitmix64(SPLITMIX_SEED + j) for j = first .. first + count - 1, as uint64."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(first, first + count, dtype=np.uint64) + np.uint64(SPLITMIX_SEED)) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def splitmix64_torch(first, count, dev):
+    """The same on the device: int64 arithmetic wraps like uint64; the logical right shifts are masked arithmetic ones."""
+    import torch
+    def lsr(x, k):
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def i64(c):
+        return c - (1 << 64) if c >= (1 << 63) else c
+    z = torch.arange(first, first + count, dtype=torch.int64, device=dev) + (SPLITMIX_SEED + i64(0x9E3779B97F4A7C15))
+    z = (z ^ lsr(z, 30)) * i64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * i64(0x94D049BB133111EB)
+    return z ^ lsr(z, 31)

@@ -150,3 +150,26 @@ def test_cxx_module_mirror_builds_and_fails_loudly_without_a_gpu(tmp_path):
         return  # the GPU suite runs it for real
     out = subprocess.run([exe, os.path.join(root, "tests", "golden", "ref")], capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "no CPU fallback" in out.stderr
+
+
+def noflags_library():
+    """build/noflags/libpzg.so: the same sources WITHOUT csrc/Makefile's two -mllvm options (tests/tools/noflags_build.sh);
+    rebuilt when a kernel source is newer.  Test infrastructure (a compiler upgrade may change what the options mean: the
+    library must be just as correct without them, only slower)."""
+    import subprocess
+    so = os.path.join(ROOT, "build", "noflags", "libpzg.so")
+    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_kernels.hip", "pzg_launch.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
+        subprocess.check_call([os.path.join(ROOT, "tests", "tools", "noflags_build.sh")])
+    return so
+
+
+def test_library_builds_without_the_mllvm_options():
+    """INTEGRATION.md says the library is "still correct" without -structurizecfg-skip-uniform-regions /
+    -align-all-nofallthru-blocks: it builds, carries a gfx950 code object and exports the same ABI (its decoding is checked
+    against the oracle on the GPU: tests/test_gpu_api.py::test_parity_of_the_build_without_the_mllvm_options)."""
+    import subprocess
+    so = noflags_library()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    assert sorted(l.split()[-1] for l in out.splitlines() if l.strip()) == declared_symbols()
+    assert b"hipv4-amdgcn-amd-amdhsa--gfx950" in open(so, "rb").read()

@@ -202,3 +202,56 @@ def test_smoke_exits_cleanly_in_a_child_process():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as e; e.smoke()"], cwd=ROOT, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_parity_of_the_build_without_the_mllvm_options(tmp_path):
+    """The speed of libpzg.so depends on two non-default LLVM options (csrc/Makefile KERNELFLAGS); its correctness must not.
+    The same sources built without them (through PZG_LIB, in a child process) against the oracle: the nine fixtures, seeded
+    valid and corrupt streams on rings 11 and 15, and the incremental protocol's event trace."""
+    import sys
+    from test_abi import noflags_library
+    so = noflags_library()
+    code = r'''
+import os, sys, zlib
+sys.path.insert(0, os.path.join(os.environ["PZG_ROOT"], "tests")); sys.path.insert(0, os.environ["PZG_ROOT"])
+import torch; torch.cuda.init()
+import corpus
+from conftest import REF_CASES, read_case
+import pure_zlib_amd as P
+from pure_zlib_amd import _ffi
+from oracle import oracle as O
+assert _ffi.LIB_PATH.endswith("build/noflags/libpzg.so"), _ffi.LIB_PATH
+ctx = P.Context(0)
+streams, want = [], []
+for name in REF_CASES:
+    z, g = read_case(name); streams.append(z); want.append(g)
+for seed in range(300):
+    d = corpus.mixed_data(200 + seed * 211 % 70000, seed) if seed % 3 else corpus.zipf_text(100 + seed * 997 % 90000, seed)
+    z = corpus.compress_variant(d, seed) if seed % 2 else zlib.compress(d, 1 + seed % 9)
+    if seed % 5 == 0: z = corpus.corrupt(z, seed)
+    streams.append(z); want.append(None)
+for ring in (11, 15):
+    ctx.set_ring_bits(ring)
+    got = P.decompress_many(streams, ctx=ctx)
+    for z, w, g in zip(streams, want, got):
+        r, o = O.decompress(z, 1 << 21)
+        if r.status == 0:
+            assert g == P.Right(o) and (w is None or o == w), ring
+        else:
+            assert (not g.is_right()) and g.value.show() == r.message.decode(), (ring, g, r.message)
+from pure_zlib_amd.incremental import Chunk, DecoderPool, NeedMore
+big = zlib.compress(corpus.zipf_text(150000, 9), 6)
+pieces = [big[i:i + 5000] for i in range(0, len(big), 5000)]
+pool = DecoderPool(1, ctx); st = pool.start(0); events = [("NeedMore",)]
+for p in pieces:
+    st = st.feed(p)
+    while isinstance(st, Chunk):
+        events.append(("Chunk", len(st.chunk))); st = st.next()
+    events.append(("NeedMore",) if isinstance(st, NeedMore) else ("Done",))
+assert events == O.trace(pieces)[0]
+pool.close(); ctx.close()
+print("noflags parity ok", len(streams))
+'''
+    env = dict(os.environ, PZG_LIB=so, PZG_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "noflags parity ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])

@@ -108,3 +108,33 @@ def test_bench_py_two_ranks_on_one_device():
     # whole-job value: both ranks' bytes over the max-over-ranks time
     assert abs(r["value"] - 2 * 4096 * 32768 / (r["ms_per_step"] * 1e-3) / 2**30) / r["value"] < 0.02
     assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
+
+
+def test_adler32_over_one_9_gib_device_buffer(gpu_ctx):
+    """BASELINE config 2 beyond 4 GiB under -m gpu: one 9 GiB device buffer, SURVEY.md 8d's splitmix64 bytes,
+    against chunked zlib.adler32 over the CPU generator's bytes (Adler32.hs:37-57: the combine step multiplies a block's
+    byte sum by the length that follows it, a 64-bit number here, modulo 65521).  Also an unaligned start and an odd length."""
+    import torch
+    dev = torch.device("cuda", 0)
+    nwords = (9 << 30) // 8
+    buf = torch.empty(nwords, dtype=torch.int64, device=dev)
+    chunk = 1 << 25  # words: 256 MiB
+    exp, exp_odd = 1, 1
+    skew, tail_cut = 5, 3  # the second checksum runs over bytes [5, 9 GiB - 3)
+    for lo in range(0, nwords, chunk):
+        cnt = min(chunk, nwords - lo)
+        buf[lo:lo + cnt] = corpus.splitmix64_torch(lo, cnt, dev)
+        host = corpus.splitmix64_numpy(lo, cnt).view(np.uint8)
+        if lo in (0, (nwords // chunk // 2) * chunk):  # device fill == CPU generator (whole chunks, two of them)
+            assert np.array_equal(buf[lo:lo + cnt].cpu().numpy().view(np.uint8), host)
+        exp = zlib.adler32(host, exp)
+        a = skew if lo == 0 else 0
+        b = len(host) - (tail_cut if lo + cnt == nwords else 0)
+        exp_odd = zlib.adler32(host[a:b], exp_odd)
+    res = torch.zeros(2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.adler32_device(buf.data_ptr(), nwords * 8, res.data_ptr(), sync=True)
+    gpu_ctx.adler32_device(buf.data_ptr() + skew, nwords * 8 - skew - tail_cut, res.data_ptr() + 4, sync=True)
+    got = res.cpu().numpy().view(np.uint32)
+    assert int(got[0]) == exp and int(got[1]) == exp_odd, (hex(int(got[0])), hex(exp), hex(int(got[1])), hex(exp_odd))
+    del buf

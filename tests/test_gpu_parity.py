@@ -259,6 +259,22 @@ def test_incremental_protocol_and_cli(gpu_ctx, tmp_path, capsys):
     out = capsys.readouterr().out
     assert "Unexpected file name." in out and "USAGE: deflate [filename]" in out
     assert "ERROR: Ran out of data mid-decompression." in out
+    # batch mode: several files, ONE decompressMany call; per file what `decompress` returns
+    datas = [corpus.zipf_text(3000 + 7919 * k, 40 + k) for k in range(5)]
+    names = []
+    for k, dk in enumerate(datas):
+        (tmp_path / f"m{k}.z").write_bytes(zlib.compress(dk, 1 + k))
+        names.append(str(tmp_path / f"m{k}.z"))
+    (tmp_path / "bad.z").write_bytes(zlib.compress(datas[0], 6)[:-5])
+    (tmp_path / "tail.z").write_bytes(zlib.compress(datas[1], 6) + b"x" * 40000)  # a whole unread lazy chunk behind the stream
+    assert deflate_cli.main(names + [str(tmp_path / "bad.z"), str(tmp_path / "note.txt"), str(tmp_path / "tail.z")]) == 0
+    for k, dk in enumerate(datas):
+        assert (tmp_path / f"m{k}").read_bytes() == dk
+    out = capsys.readouterr().out
+    assert "bad.z: ERROR: Decompression error: Ran out of data mid-decompression 2." in out
+    assert "note.txt: Unexpected file name." in out
+    assert "tail.z: ERROR: Decompression error: Finished with data remaining." in out
+    assert not (tmp_path / "bad").exists() and not (tmp_path / "tail").exists()
 
 
 def test_benchmark_harness_groups(gpu_ctx, capsys):
