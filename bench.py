@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gzip", action="store_true", help="diagnostic: the same payloads as RFC 1952 members (extension; CRC-32 pass on the device)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--incremental-decoders", type=int, default=4096, help="decoders of the incremental-path leg (pzg_decoder_feed, 32 KiB pieces); 0 = skip")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -337,6 +338,16 @@ def main():
                     "pinned staging + PCIe both ways + kernel, one call",
         }
         del h_out
+
+    # ---- the incremental path (Benchmark.hs:53-70): 4,096 resumable decoders fed 32 KiB pieces,
+    # host buffers both ways, one launch per feed call.  Reported beside `value`, never as it.
+    if rank == 0 and world == 1 and args.incremental_decoders > 0 and not args.no_host_path:
+        from pure_zlib_amd import benchmark as HB
+        inc_plain = [corpus.zipf_text(256 * 1024, 7000 + k) for k in range(32)]
+        inc_z = [zlib.compress(t, 6) for t in inc_plain]
+        result["incremental_variant"] = HB.incremental_throughput(ctx, inc_z, inc_plain, n_decoders=args.incremental_decoders)
+        result["incremental_variant"]["note"] = ("pzg_decoder_feed: resumable decoders on the device (32 KiB LDS ring instance, 4 per CU), "
+                                                 "256 KiB level-6 text streams; time = the feed calls only (pack + H2D + launch + D2H + copy-out)")
 
     # ---- CPU baseline, rank 0 at N=1 only: the oracle ("port": the bit-at-a-time restatement of pure-zlib) and system
     # zlib, on this box's host cores.  All cores: the WHOLE timed batch.  One thread: a bounded sample of it (the whole

@@ -115,7 +115,8 @@ PZG_API int  pzg_init(int device, pzg_ctx **out);
  * selects HIP device d, 0 selects every visible device.  One call of pzg_decompress_many() with HOST pointers then
  * partitions the streams over the devices (longest-processing-time-first by capacity), one host thread, HIP stream set
  * and staging arenas per device, and every result lands in the caller's own out_off[] / status[] slots: the streams
- * are independent, so nothing crosses between devices (no collective).  PZG_DEVICE_PTRS calls need a one-device context. */
+ * are independent, so nothing crosses between devices (no collective).  PZG_DEVICE_PTRS calls of pzg_decompress_many need a
+ * one-device context; data that already lives on several devices goes through pzg_decompress_many_sharded(). */
 PZG_API int  pzg_init_mask(uint32_t device_mask, pzg_ctx **out);
 PZG_API int  pzg_device_count(pzg_ctx *ctx);  /* devices (shards) of the context */
 /* Drop the caller's reference (see "Lifetimes" above): synchronises, invalidates the handle, frees everything unless
@@ -165,6 +166,27 @@ PZG_API int pzg_decompress_many(pzg_ctx *ctx,
                         uint64_t *out_len, int32_t *status, uint32_t *detail,
                         uint64_t *in_used, uint32_t *adler,
                         uint32_t n, uint32_t flags);
+
+/*
+ * decompressMany over several devices with the data ALREADY on them: a context from
+ * pzg_init_mask() has one shard per device; batch b names its shard (0 .. pzg_device_count()-1) and carries pointers that
+ * are all device memory of THAT shard's device, with the meaning they have in pzg_decompress_many().  Every batch is
+ * enqueued on its own device's stream -- nothing crosses PCIe or xGMI, no collective: the streams are independent -- and
+ * the call returns when all of them have finished (with PZG_ASYNC: at once; pzg_sync() waits for every device).
+ * Several batches may name the same shard (they run one after the other on its stream).  flags: PZG_ASYNC, PZG_GZIP,
+ * PZG_LPT_ORDER (PZG_DEVICE_PTRS is implied).
+ */
+typedef struct pzg_device_batch {
+    uint32_t shard;  /* which device of the context the pointers below live on */
+    uint32_t n;      /* streams in this batch */
+    const uint8_t *in_base; const uint64_t *in_off, *in_len;
+    uint8_t *out_base;      const uint64_t *out_off, *out_cap;
+    uint64_t *out_len; int32_t *status;
+    uint32_t *detail;   /* 2n or NULL */
+    uint64_t *in_used;  /* n or NULL */
+    uint32_t *adler;    /* n or NULL */
+} pzg_device_batch;
+PZG_API int pzg_decompress_many_sharded(pzg_ctx *ctx, const pzg_device_batch *batches, uint32_t nbatches, uint32_t flags);
 
 /*
  * EXTENSION -- preset dictionaries (RFC 1950 FDICT).  The reference skips DICTID and decodes with an empty history

@@ -42,10 +42,18 @@ DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares
 SYMBOLS = [
-    "pzg_init", "pzg_init_mask", "pzg_device_count", "pzg_adler32_many", "pzg_decompress_many_dict",
+    "pzg_init", "pzg_init_mask", "pzg_device_count", "pzg_adler32_many", "pzg_decompress_many_dict", "pzg_decompress_many_sharded",
     "pzg_decoder_create", "pzg_decoder_destroy", "pzg_decoder_reset", "pzg_decoder_feed", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
     "pzg_adler32", "pzg_error_message", "pzg_last_kernel_ms", "pzg_strerror", "pzg_last_error", "pzg_version",
 ]
+
+
+class DeviceBatch(C.Structure):
+    """pzg_device_batch (include/pzg.h): one shard's share of a pzg_decompress_many_sharded call, device pointers as integers."""
+    _fields_ = [("shard", C.c_uint32), ("n", C.c_uint32),
+                ("in_base", C.c_void_p), ("in_off", C.c_void_p), ("in_len", C.c_void_p),
+                ("out_base", C.c_void_p), ("out_off", C.c_void_p), ("out_cap", C.c_void_p),
+                ("out_len", C.c_void_p), ("status", C.c_void_p), ("detail", C.c_void_p), ("in_used", C.c_void_p), ("adler", C.c_void_p)]
 
 
 class PzgError(RuntimeError):
@@ -90,6 +98,8 @@ def lib():
     L.pzg_decompress_many_dict.argtypes = [C.c_void_p, vp, u64p, u64p, vp, u64p, u64p, vp, u64p, u64p, u64p, i32p, u32p, u64p, u32p,
                                            C.c_uint32, C.c_uint32]
     L.pzg_decompress_many_dict.restype = C.c_int
+    L.pzg_decompress_many_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.pzg_decompress_many_sharded.restype = C.c_int
     L.pzg_decoder_create.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.pzg_decoder_create.restype = C.c_int
     L.pzg_decoder_destroy.argtypes = [C.c_void_p]

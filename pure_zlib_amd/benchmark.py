@@ -30,6 +30,89 @@ DEFAULT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 READ_CHUNK = 32768  # L.readFile hands out defaultChunkSize pieces
 
 
+def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_decoders: int = 4096, piece: int = 32768,
+                           room: int = 192 * 1024) -> Dict[str, object]:
+    """Throughput of the incremental path (Benchmark.hs:53-70 benches `decompressIncremental` per fixture; this is its
+    batched form): n_decoders resumable decoders, decoder k on streams[k % len(streams)], every one fed `piece` input
+    bytes per pzg_decoder_feed call -- one launch per call, host buffers both ways.  Only the feed calls are timed (the
+    host-side bookkeeping a caller does between feeds -- unconsumed tails in front of the next pieces -- is not).  Every
+    decoder's output is compared with plain[k % len(plain)].  Two passes over fresh decoders: the first sizes the
+    library's page-locked staging, the second is the one reported."""
+    import ctypes as C
+    import numpy as np
+    from . import _ffi
+    L = _ffi.lib()
+    h = C.c_void_p()
+    _ffi.check(L.pzg_decoder_create(ctx.handle, n_decoders, C.byref(h)), ctx.handle)
+    P = len(streams)
+
+    def one_pass():
+        _ffi.check(L.pzg_decoder_reset(h, None, 0), ctx.handle)
+        fed = [0] * n_decoders                # input bytes handed over so far (incl. those still in the tail)
+        tails = [b""] * n_decoders
+        outs = [bytearray() for _ in range(n_decoders)]
+        done = np.zeros(n_decoders, dtype=bool)
+        out_cap = np.full(n_decoders, room, dtype=np.uint64)
+        out_off = np.arange(n_decoders, dtype=np.uint64) * np.uint64(room)
+        out_buf = np.zeros(n_decoders * room + 16, dtype=np.uint8)
+        t_calls, n_calls, n_feeds, out_full = 0.0, 0, 0, 0
+        while not done.all():
+            active = np.nonzero(~done)[0]
+            m = len(active)
+            parts = []
+            for k in active:
+                z = streams[k % P]
+                if len(tails[k]) < piece and fed[k] < len(z):  # NeedMore: the next piece behind the unconsumed tail
+                    nxt = z[fed[k]:fed[k] + piece]
+                    fed[k] += len(nxt)
+                    tails[k] = tails[k] + nxt
+                parts.append(tails[k])
+            in_len = np.array([len(p_) for p_ in parts], dtype=np.uint64)
+            in_off = np.zeros(m, dtype=np.uint64)
+            in_off[1:] = np.cumsum(in_len[:-1])
+            in_buf = np.frombuffer(b"".join(parts) + b"\0" * 16, dtype=np.uint8)
+            idx = active.astype(np.uint32)
+            fin = np.array([1 if fed[k] >= len(streams[k % P]) else 0 for k in active], dtype=np.uint8)
+            o_len = np.zeros(m, dtype=np.uint64)
+            state = np.zeros(m, dtype=np.int32)
+            detail = np.zeros((m, 2), dtype=np.uint32)
+            used = np.zeros(m, dtype=np.uint64)
+            chunks = np.zeros(m, dtype=np.uint32)
+            t0 = time.perf_counter()
+            rc = L.pzg_decoder_feed(h, idx.ctypes.data, m, in_buf.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, fin.ctypes.data,
+                                    out_buf.ctypes.data, out_off[:m].ctypes.data, out_cap[:m].ctypes.data, o_len.ctypes.data,
+                                    state.ctypes.data, detail.ctypes.data, used.ctypes.data, chunks.ctypes.data, None)
+            t_calls += time.perf_counter() - t0
+            _ffi.check(rc, ctx.handle)
+            n_calls += 1
+            n_feeds += m
+            for j, k in enumerate(active):
+                outs[k] += out_buf[int(out_off[j]):int(out_off[j]) + int(o_len[j])].tobytes()
+                tails[k] = parts[j][int(used[j]):]
+                st = int(state[j])
+                if st == _ffi.DEC_OUT_FULL:
+                    out_full += 1
+                elif st != _ffi.DEC_NEED_INPUT:
+                    if st != _ffi.OK:
+                        raise RuntimeError(f"decoder {k}: status {st}")
+                    done[k] = True
+        ok = all(bytes(outs[k]) == plain[k % P] for k in range(n_decoders))
+        total = sum(len(o) for o in outs)
+        return {"decoders": n_decoders, "piece_bytes": piece, "room_bytes": room, "feed_calls": n_calls, "decoder_feeds": n_feeds,
+                "out_full_resumes": out_full, "decoded_MiB": round(total / 2**20, 1), "seconds_in_feed_calls": round(t_calls, 4),
+                "GiBps": round(total / t_calls / 2**30, 2), "ms_per_feed_call": round(t_calls / n_calls * 1e3, 2),
+                "us_per_decoder_feed": round(t_calls / n_feeds * 1e6, 2), "ok": bool(ok)}
+
+    try:
+        first = one_pass()
+        res = one_pass()
+        res["ok"] = bool(res["ok"] and first["ok"])
+        res["first_pass_GiBps"] = first["GiBps"]
+        return res
+    finally:
+        L.pzg_decoder_destroy(h)
+
+
 def find_cases(directory: str) -> List[str]:
     """Names with both <name>.z and <name>.gold present, sorted (Benchmark.hs:12-24 lists them by hand)."""
     names = sorted(f[:-2] for f in os.listdir(directory) if f.endswith(".z"))

@@ -936,6 +936,51 @@ int pzg_decompress_many_dict(pzg_ctx *ctx, const uint8_t *in_base, const uint64_
     }
 }
 
+int pzg_decompress_many_sharded(pzg_ctx *ctx, const pzg_device_batch *batches, uint32_t nbatches, uint32_t flags)
+{
+    if (!ctx_live(ctx) || (!batches && nbatches)) return PZG_RC_BAD_ARG;
+    if (flags & ~(PZG_ASYNC | PZG_GZIP | PZG_LPT_ORDER | PZG_DEVICE_PTRS)) return PZG_RC_BAD_ARG;
+    for (uint32_t b = 0; b < nbatches; ++b) {
+        const pzg_device_batch &q = batches[b];
+        if (q.shard >= ctx->shards.size()) return PZG_RC_BAD_ARG;
+        if (q.n && (!q.in_base || !q.in_off || !q.in_len || !q.out_base || !q.out_off || !q.out_cap || !q.out_len || !q.status))
+            return PZG_RC_BAD_ARG;
+    }
+    try {
+        // every batch enqueued on its own device's stream first (launches are asynchronous: one host thread feeds them all) ...
+        int rc = PZG_RC_OK;
+        for (uint32_t b = 0; b < nbatches && rc == PZG_RC_OK; ++b) {
+            const pzg_device_batch &q = batches[b];
+            if (q.n == 0) continue;
+            pzg::InflateArgs a{};
+            a.in_base = q.in_base;
+            a.in_off = q.in_off;
+            a.in_len = q.in_len;
+            a.out_base = q.out_base;
+            a.out_off = q.out_off;
+            a.out_cap = q.out_cap;
+            a.out_len = q.out_len;
+            a.status = q.status;
+            a.detail = q.detail;
+            a.in_used = q.in_used;
+            a.adler = q.adler;
+            a.n = q.n;
+            rc = launch_device(ctx, *ctx->shards[q.shard], a, (flags & (PZG_GZIP | PZG_LPT_ORDER)) | PZG_DEVICE_PTRS | PZG_ASYNC);
+        }
+        // ... then waited for, unless the caller does that (on an error too: nothing enqueued may outlive a failed call)
+        if (!(flags & PZG_ASYNC) || rc != PZG_RC_OK) {
+            for (auto &s : ctx->shards) {
+                std::lock_guard<std::mutex> g(s->mu);
+                if (hipSetDevice(s->device) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess)
+                    if (rc == PZG_RC_OK) rc = PZG_RC_HIP_ERROR;
+            }
+        }
+        return rc;
+    } catch (...) {
+        return PZG_RC_NO_MEMORY;
+    }
+}
+
 // ---- resumable decoders (decompressIncremental) ---------------------------------------------------------------------
 }  // extern "C"
 
@@ -947,6 +992,7 @@ struct pzg_decoder {
     uint8_t *d_state = nullptr;  // n x stride: ResumeState + LDS image per decoder
     uint32_t *d_counter = nullptr;
     Arena d_in, d_out, d_meta;
+    Pinned h_in, h_out, h_meta;  // page-locked staging (grow-only): the copies run at link speed and really are asynchronous
     hipStream_t stream = nullptr;
     std::mutex mu;
 };
@@ -997,6 +1043,8 @@ void pzg_decoder_destroy(pzg_decoder *dec)
     if (dec->stream) (void)hipStreamSynchronize(dec->stream);
     for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta})
         if (a->p) (void)hipFree(a->p);
+    for (Pinned *h : {&dec->h_in, &dec->h_out, &dec->h_meta})
+        if (h->p) (void)hipHostFree(h->p);
     if (dec->d_state) (void)hipFree(dec->d_state);
     if (dec->d_counter) (void)hipFree(dec->d_counter);
     if (dec->stream) (void)hipStreamDestroy(dec->stream);
@@ -1045,12 +1093,16 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
             if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return PZG_RC_BAD_ARG;
         }
         std::lock_guard<std::mutex> g(dec->mu);
-        Shard &sh = *ctx->shards[0];
-        HIP_TRY(ctx, hipSetDevice(sh.device));
-        // packed staging: inputs, output room, meta (in_off | in_len | out_off | out_cap | out_len | in_used : u64[m];
-        // state | adler | chunks : 32-bit [m]; detail u32[2m]; final u8[m])
-        std::vector<uint64_t> meta(4 * (size_t)m);
-        uint64_t *ioff = meta.data(), *ilen = ioff + m, *ooff = ilen + m, *ocap = ooff + m;
+        const int num_cus = ctx->shards[0]->num_cus;
+        HIP_TRY(ctx, hipSetDevice(dec->device));
+        // Packed staging in page-locked memory.  One meta block, both ways:
+        //   in_off | in_len | out_off | out_cap : u64[m]   (host -> device)
+        //   out_len | in_used : u64[m]; state | adler | chunks : 32-bit [m]; detail u32[2m]   (device -> host)
+        //   final u8[m]   (host -> device)
+        const size_t meta_bytes = 72 * (size_t)m + 64;
+        int rc;
+        if ((rc = pinned_reserve(ctx, dec->h_meta, meta_bytes)) != PZG_RC_OK) return rc;
+        uint64_t *ioff = (uint64_t *)dec->h_meta.p, *ilen = ioff + m, *ooff = ilen + m, *ocap = ooff + m;
         size_t ip = 0, op = 0;
         for (uint32_t j = 0; j < m; ++j) {
             ioff[j] = ip;
@@ -1060,22 +1112,27 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
             ocap[j] = out_cap[j];
             op += pad16(out_cap[j]);
         }
-        std::vector<uint8_t> hin(ip + 16);
-        for (uint32_t j = 0; j < m; ++j)
-            if (ilen[j]) memcpy(hin.data() + ioff[j], in_base + in_off[j], ilen[j]);
-        int rc;
-        const size_t meta_bytes = 72 * (size_t)m + 64;
+        uint8_t *h_final = dec->h_meta.p + 68 * (size_t)m;
+        if (final_in) memcpy(h_final, final_in, m);
+        else memset(h_final, 0, m);
+        if ((rc = pinned_reserve(ctx, dec->h_in, ip + 64)) != PZG_RC_OK) return rc;
+        if ((rc = pinned_reserve(ctx, dec->h_out, op + 64)) != PZG_RC_OK) return rc;
         if ((rc = arena_reserve(ctx, dec->d_in, ip + 64)) != PZG_RC_OK) return rc;
         if ((rc = arena_reserve(ctx, dec->d_out, op + 64)) != PZG_RC_OK) return rc;
         if ((rc = arena_reserve(ctx, dec->d_meta, meta_bytes)) != PZG_RC_OK) return rc;
+        // the decoders' inputs, packed by the context's helper threads (a batch of thousands of decoders moves 100+ MiB)
+        const unsigned parts = ip >= (8u << 20) ? ctx->helpers->size() : 1u;
+        uint8_t *hin = dec->h_in.p;
+        ctx->helpers->run(parts, [&](unsigned part, unsigned nparts) {
+            for (uint32_t j = (uint32_t)((uint64_t)m * part / nparts), e = (uint32_t)((uint64_t)m * (part + 1) / nparts); j < e; ++j)
+                if (ilen[j]) memcpy(hin + ioff[j], in_base + in_off[j], ilen[j]);
+        });
         uint8_t *dm = (uint8_t *)dec->d_meta.p;
         hipStream_t st = dec->stream;
-        HIP_TRY(ctx, hipMemcpyAsync(dm, meta.data(), 32 * (size_t)m, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(dec->d_in.p, hin.data(), ip, hipMemcpyHostToDevice, st));
-        std::vector<uint8_t> fin(m, 0);
-        if (final_in) memcpy(fin.data(), final_in, m);
+        HIP_TRY(ctx, hipMemcpyAsync(dm, dec->h_meta.p, 32 * (size_t)m, hipMemcpyHostToDevice, st));
         uint8_t *d_final = dm + 68 * (size_t)m;
-        HIP_TRY(ctx, hipMemcpyAsync(d_final, fin.data(), m, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(d_final, h_final, m, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dec->d_in.p, hin, ip, hipMemcpyHostToDevice, st));
         pzg::ResumeArgs a{};
         a.state_stride = dec->stride;
         a.in_base = (const uint8_t *)dec->d_in.p;
@@ -1114,16 +1171,38 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
             r.detail += 2 * (size_t)j0;
             r.final_in += j0;
             r.n = j1 - j0;
-            HIP_TRY(ctx, pzg::launch_resume(r, sh.num_cus, st));
+            HIP_TRY(ctx, pzg::launch_resume(r, num_cus, st));
             j0 = j1;
         }
-        std::vector<uint8_t> res(36 * (size_t)m), hout(op + 16);
-        HIP_TRY(ctx, hipMemcpyAsync(res.data(), dm + 32 * (size_t)m, 36 * (size_t)m, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(hout.data(), dec->d_out.p, op, hipMemcpyDeviceToHost, st));
+        // results first (36 bytes per decoder), then only what the decoders delivered: a decoder's room is out_cap, what it
+        // fills of it is usually far less -- one copy over the whole room when most of it is used, else one per decoder run
+        uint8_t *res = dec->h_meta.p + 32 * (size_t)m;
+        HIP_TRY(ctx, hipMemcpyAsync(res, dm + 32 * (size_t)m, 36 * (size_t)m, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
-        const uint64_t *olen = (const uint64_t *)res.data(), *used = olen + m;
+        const uint64_t *olen = (const uint64_t *)res, *used = olen + m;
         const int32_t *stt = (const int32_t *)(used + m);
         const uint32_t *ad = (const uint32_t *)(stt + m), *ch = ad + m, *det = ch + m;
+        uint8_t *hout = dec->h_out.p;
+        uint64_t delivered = 0;
+        for (uint32_t j = 0; j < m; ++j) delivered += olen[j] <= ocap[j] ? olen[j] : ocap[j];
+        bool same_room = true;
+        uint64_t most = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            same_room = same_room && ocap[j] == ocap[0];
+            const uint64_t dj = olen[j] <= ocap[j] ? olen[j] : ocap[j];
+            most = dj > most ? dj : most;
+        }
+        if (delivered == 0) {
+            // nothing to fetch
+        } else if (delivered * 4 >= op * 3 || (!same_room && m > 64u)) {
+            HIP_TRY(ctx, hipMemcpyAsync(hout, dec->d_out.p, op, hipMemcpyDeviceToHost, st));
+        } else if (same_room) {  // equal rooms (the mirrors' case): one strided copy of the used part of every room
+            HIP_TRY(ctx, hipMemcpy2DAsync(hout, pad16(ocap[0]), dec->d_out.p, pad16(ocap[0]), pad16(most), m, hipMemcpyDeviceToHost, st));
+        } else {
+            for (uint32_t j = 0; j < m; ++j)
+                if (olen[j]) HIP_TRY(ctx, hipMemcpyAsync(hout + ooff[j], (const uint8_t *)dec->d_out.p + ooff[j], pad16(olen[j] <= ocap[j] ? olen[j] : ocap[j]), hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(st));
         for (uint32_t j = 0; j < m; ++j) {
             out_len[j] = olen[j];
             state[j] = stt[j];
@@ -1134,8 +1213,11 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                 detail[2 * (size_t)j] = det[2 * (size_t)j];
                 detail[2 * (size_t)j + 1] = det[2 * (size_t)j + 1];
             }
-            if (olen[j]) memcpy(out_base + out_off[j], hout.data() + ooff[j], olen[j]);
         }
+        ctx->helpers->run(delivered >= (8u << 20) ? ctx->helpers->size() : 1u, [&](unsigned part, unsigned nparts) {
+            for (uint32_t j = (uint32_t)((uint64_t)m * part / nparts), e = (uint32_t)((uint64_t)m * (part + 1) / nparts); j < e; ++j)
+                if (olen[j]) memcpy(out_base + out_off[j], hout + ooff[j], olen[j] <= ocap[j] ? olen[j] : ocap[j]);
+        });
         return PZG_RC_OK;
     } catch (const std::bad_alloc &) {
         return PZG_RC_NO_MEMORY;

@@ -239,6 +239,17 @@ class Context:
                                          status, detail or None, in_used or None, adler or None, n, flags)
         _ffi.check(rc, self._h)
 
+    def decompress_many_sharded(self, batches, sync: bool = True, gzip: bool = False, lpt: bool = False):
+        """pzg_decompress_many_sharded: `batches` is a list of dicts (shard, n, in_base, in_off, in_len, out_base, out_off,
+        out_cap, out_len, status and optionally detail, in_used, adler), every pointer an integer address of device memory
+        on that shard's device.  One call enqueues them all; nothing leaves the devices."""
+        arr = (_ffi.DeviceBatch * len(batches))()
+        for q, b in zip(arr, batches):
+            for k, _t in _ffi.DeviceBatch._fields_:
+                setattr(q, k, b.get(k) or 0)
+        flags = (0 if sync else _ffi.ASYNC) | (_ffi.GZIP if gzip else 0) | (_ffi.LPT_ORDER if lpt else 0)
+        _ffi.check(self._L.pzg_decompress_many_sharded(self._h, C.byref(arr) if len(batches) else None, len(batches), flags), self._h)
+
     def adler32(self, data, init: int = 1) -> int:
         arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         out = C.c_uint32(0)

@@ -255,3 +255,52 @@ print("noflags parity ok", len(streams))
     env = dict(os.environ, PZG_LIB=so, PZG_ROOT=ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "noflags parity ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_decompress_many_sharded_device_pointers(gpu_ctx, oracle, monkeypatch):
+    """pzg_decompress_many_sharded: data ALREADY on the devices -- one batch of device pointers per
+    shard, every batch enqueued on its own device's stream by one call, nothing staged through the host.  Three shards
+    folded onto device 0 (the test knob), four batches (two on one shard), synchronous and PZG_ASYNC + pzg_sync; every
+    stream against the plaintext, samples against the oracle; bad arguments refused."""
+    import pure_zlib_amd as P
+    from devbatch import DeviceBatch
+    from pure_zlib_amd._ffi import PzgError
+    monkeypatch.setenv("PZG_FOLD_DEVICES", "0")
+    group = P.Context(device_mask=0b111)
+    try:
+        texts = [corpus.zipf_text(1024 * (1 + (k * 37) % 48), k) for k in range(256)]
+        zs = [zlib.compress(t, 6) for t in texts]
+        rng = np.random.default_rng(3)
+        parts = [DeviceBatch(texts, zs, rng.integers(0, len(zs), size=n)) for n in (5000, 3000, 7000, 11)]
+        shard_of = [0, 1, 2, 1]
+
+        def as_batches():
+            return [dict(shard=s, n=b.n, in_base=b.d_in.data_ptr(), in_off=b.d_in_off.data_ptr(), in_len=b.d_in_len.data_ptr(),
+                         out_base=b.d_out.data_ptr(), out_off=b.d_out_off.data_ptr(), out_cap=b.d_out_cap.data_ptr(),
+                         out_len=b.d_out_len.data_ptr(), status=b.d_status.data_ptr(), detail=b.d_detail.data_ptr(),
+                         in_used=b.d_in_used.data_ptr(), adler=b.d_adler.data_ptr()) for s, b in zip(shard_of, parts)]
+
+        def results(b):
+            return (b.d_status.cpu().numpy(), b.d_out_len.cpu().numpy(), b.d_in_used.cpu().numpy(), b.d_adler.cpu().numpy().view(np.uint32))
+        for sync in (True, False):
+            for b in parts:
+                b.d_out.fill_(0xCD)
+                b.d_status.fill_(-1)
+            b.torch.cuda.synchronize()
+            group.decompress_many_sharded(as_batches(), sync=sync, lpt=not sync)
+            if not sync:
+                group.sync()
+            for b in parts:
+                b.check_all(*results(b))
+            parts[0].check_sample_vs_oracle(oracle, 64)
+        bad = as_batches()
+        bad[1]["shard"] = 3
+        with pytest.raises(PzgError):
+            group.decompress_many_sharded(bad)
+        bad = as_batches()
+        bad[2]["status"] = 0
+        with pytest.raises(PzgError):
+            group.decompress_many_sharded(bad)
+        group.decompress_many_sharded([])
+    finally:
+        group.close()

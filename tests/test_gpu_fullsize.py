@@ -86,9 +86,7 @@ def test_config5_per_gpu_share_131072_mixed_blobs(gpu_ctx, oracle):
     b.check_sample_vs_oracle(oracle, 256)
 
 
-def test_bench_py_two_ranks_on_one_device():
-    """The real N>1 path of bench.py: torch.distributed.run launches two ranks before anything touches the GPU; each
-    decodes its own shard through libpzg.so, the time is MAX-reduced, bit_exact MIN-reduced, rank 0 prints the line."""
+def _bench_two_ranks(extra):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -97,17 +95,33 @@ def test_bench_py_two_ranks_on_one_device():
                PZG_BENCH_DEVICE="0", PZG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--streams", "4096", "--pool", "256"]
+           "--pool", "256"] + extra
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # ONE line, from rank 0
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["bit_exact"] is True and r["scaling"] == "weak"
+    return r
+
+
+def test_bench_py_two_ranks_on_one_device():
+    """The real N>1 path of bench.py: torch.distributed.run launches two ranks before anything touches the GPU; each
+    decodes its own shard through libpzg.so, the time is MAX-reduced, bit_exact MIN-reduced, rank 0 prints the line."""
+    r = _bench_two_ranks(["--streams", "4096"])
     assert r["config"]["streams_per_gpu"] == 4096 and r["config"]["parallelism"] == "shard2"
     # whole-job value: both ranks' bytes over the max-over-ranks time
     assert abs(r["value"] - 2 * 4096 * 32768 / (r["ms_per_step"] * 1e-3) / 2**30) / r["value"] < 0.02
     assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
+
+
+def test_bench_py_config5_command_two_ranks():
+    """BASELINE config 5's command -- `bench.py --gpus 8 --workload mixed --streams 131072` (131,072 mixed 1-64 KiB level-6
+    streams per GPU, 1 M on the node) -- with two ranks folded onto device 0 and a smaller per-rank share: the LPT shard
+    plan over mixed sizes, every stream compared with its plaintext on each rank."""
+    r = _bench_two_ranks(["--workload", "mixed", "--streams", "16384"])
+    assert r["config"]["streams_per_gpu"] == 16384 and r["config"]["parallelism"] == "shard2"
+    assert "config 5" in r["config"]["workload"] and r["value"] > 0
 
 
 def test_adler32_over_one_9_gib_device_buffer(gpu_ctx):
