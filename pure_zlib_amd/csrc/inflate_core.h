@@ -1626,7 +1626,9 @@ struct Decoder {
         if (HYBRID) {  // sources older than the ring: the stream's own flushed output (fdelta = op - flushed)
             PZG_LANES_BEGIN(j)
                 const uint32_t off = lane_bit(farm, j) ? 32768u + fdelta + (o0 + j) - PZG_LV(DIST, j) : 32768u;
-#if PZG_DEVICE_PASS
+#if PZG_DEVICE_PASS && defined(PZG_FAR_NO_NT)   // experiment: far reads as plain (cached) loads
+                PZG_LV(pendF, j) = far_base[off];
+#elif PZG_DEVICE_PASS
                 PZG_LV(pendF, j) = __builtin_nontemporal_load(far_base + off);
 #else
                 PZG_LV(pendF, j) = off != 32768u ? far_base[off] : (uint8_t)0;

@@ -304,3 +304,36 @@ def test_decompress_many_sharded_device_pointers(gpu_ctx, oracle, monkeypatch):
         group.decompress_many_sharded([])
     finally:
         group.close()
+
+
+def test_host_path_pipelined_ranges_back_to_back_extents(gpu_ctx):
+    """The host-pointer path on a batch large enough for several pipelined ranges (192 MiB of output), extents back to back
+    and not page aligned: every stream against its plaintext, a truncated stream and one that outgrows its capacity among
+    them, and the bytes in front of and behind the extents untouched.  (Round 3 tried downloading such spans straight into
+    the caller's arena -- page-locked for the copy -- instead of through pinned staging: measured slower)"""
+    texts = [corpus.zipf_text(16384, k) for k in range(512)]
+    zs = [zlib.compress(t, 6) for t in texts]
+    pick = np.random.default_rng(11).integers(0, len(zs), size=12288)
+    streams = [zs[k] for k in pick]
+    streams[77] = streams[77][:-9]                      # truncated
+    streams[4000] = zlib.compress(texts[3] * 2, 6)      # outgrows its capacity (PZG_E_OUT_TOO_SMALL)
+    n = len(streams)
+    in_len = np.array([len(s) for s in streams], dtype=np.uint64)
+    in_off = np.zeros(n, dtype=np.uint64)
+    in_off[1:] = np.cumsum((in_len[:-1] + 15) // 16 * 16)
+    in_buf = np.zeros(int(in_off[-1] + in_len[-1]) + 16, dtype=np.uint8)
+    for k, s in enumerate(streams):
+        in_buf[int(in_off[k]):int(in_off[k]) + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    guard = 4096 + 48
+    out_cap = np.full(n, 16384, dtype=np.uint64)
+    out_off = guard + np.arange(n, dtype=np.uint64) * np.uint64(16384)
+    out_buf = np.full(guard + n * 16384 + guard, 0xCD, dtype=np.uint8)
+    out_len, status, _detail, _used, _adler = gpu_ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap)
+    assert (out_buf[:guard] == 0xCD).all() and (out_buf[-guard:] == 0xCD).all()
+    assert status[77] == 1 and status[4000] == 14 and int(out_len[4000]) == 32768
+    good = np.ones(n, dtype=bool)
+    good[[77, 4000]] = False
+    assert (status[good] == 0).all()
+    body = out_buf[guard:guard + n * 16384].reshape(n, 16384)
+    pool = np.frombuffer(b"".join(texts), dtype=np.uint8).reshape(len(texts), 16384)
+    assert np.array_equal(body[good], pool[pick][good])

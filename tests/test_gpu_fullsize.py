@@ -120,7 +120,7 @@ def test_bench_py_config5_command_two_ranks():
     streams per GPU, 1 M on the node) -- with two ranks folded onto device 0 and a smaller per-rank share: the LPT shard
     plan over mixed sizes, every stream compared with its plaintext on each rank."""
     r = _bench_two_ranks(["--workload", "mixed", "--streams", "16384"])
-    assert r["config"]["streams_per_gpu"] == 16384 and r["config"]["parallelism"] == "shard2"
+    assert 14000 < r["config"]["streams_per_gpu"] < 19000 and r["config"]["parallelism"] == "shard2"  # (balanced by bytes, not by count)
     assert "config 5" in r["config"]["workload"] and r["value"] > 0
 
 
