@@ -1839,6 +1839,14 @@ struct Decoder {
     // for leaving passes through an opaque statement (nothing can be threaded from inside the loop to the handlers), so it
     // stays a region of plain scalar branches.  HL_WINDOW: the window decoded last (TK0, TK1, S0, S1, k0, k1) is one for
     // window2_rare(); HL_GENERAL: the general token loop has to take a step (stream tail, flush, copy_match).
+    // Round 3 tried to take scalar work out of this loop (one compare per window for the cursor, one for the queue, use_sub a
+    // template argument: -2 % scalar, -11 % branch instructions by the counters) and measured no gain (DESIGN.md 8,
+    // profiles/r03_costmodel.txt); two things learnt on the way, for whoever edits it next: (1) every way out must be a
+    // `break` to the ONE block behind the loop with its reason in `why` -- give the exits blocks of their own, or put an inner
+    // loop with two ways out inside, and the compiler funnels them through a dispatch variable that EVERY iteration sets and
+    // tests; (2) a uniform value the register allocator parks in a vector register (the scalar file is full here) makes its
+    // compare a vector compare and the branch, and with it the whole region, divergent for the structurizer: pass such
+    // operands through uni() at the compare, as window2_ok() does.
     enum : uint32_t { HL_GENERAL = 1, HL_WINDOW = 2 };
     template <bool FX>
     PZG_FN uint32_t hot_loop(LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TK1, uint64_t &S0, uint64_t &S1, uint32_t &k0, uint32_t &k1)
