@@ -462,7 +462,10 @@ struct Decoder {
     // the ring ("far") are requested from HBM/L2 and stored only when the next segment starts (complete_pending),
     // so the far-read latency overlaps the decode of the next windows instead of stalling the wave.
     const uint8_t *far_base;    // far reads: far_base + 32768 is produced-byte `flushed` (or the input, see set_far_base)
-    uint64_t far_okmask;        // all ones while far reads may touch the output (flushed < cap), else 0
+    uint64_t far_okmask;        // all ones while far reads may touch the output (128 <= flushed < cap), else 0
+    // What a lane with no far source reads (the far load is unconditional: see segment_store): a byte one whole cache
+    // line or more below `flushed` -- or the stream's first input byte while nothing may be read from the output.
+    static constexpr uint32_t FAR_IDLE = 32768u - 128u;
     uint64_t pend_m0, pend_m1;  // lanes of the last segment's two 64-byte passes whose byte is still on its way (0 = none)
     uint32_t pend_pos;          // those bytes belong at ring position pend_pos + 64 * pass + lane
     LaneVec<uint8_t> pendF0, pendF1;   // the far bytes (valid in the lanes of pend_m0 / pend_m1); bytes, so that nothing
@@ -646,9 +649,17 @@ struct Decoder {
         }
         // weight of byte i of vector j = it*WAVE + lane is  n - 16 j - i
         //   = (n - 16 lane - 16) - 16*WAVE*it + (16 - i)
-        int64_t bl = (int64_t)((int64_t)n - 16 * (int64_t)lane - 16) * (int64_t)a_l + (int64_t)w_l -
-                     (int64_t)(16u * PZG_WAVE) * (int64_t)u_l;
-        uint32_t bl_mod = (uint32_t)((uint64_t)bl % ADLER_MOD);
+        uint32_t bl_mod;
+        if (PZG_WAVE == 64u && RING_BITS <= 13) {
+            // (device, small rings: n <= 8 KiB, a lane sees at most 8 vectors, so every term is below 2^29 and the sum -- a
+            // sum of positive weights times bytes -- is not negative: 32-bit arithmetic, a third of the registers)
+            const uint32_t bl32 = (n - 16u * lane - 16u) * (uint32_t)a_l + (uint32_t)w_l - (16u * PZG_WAVE) * (uint32_t)u_l;
+            bl_mod = bl32 % ADLER_MOD;
+        } else {
+            int64_t bl = (int64_t)((int64_t)n - 16 * (int64_t)lane - 16) * (int64_t)a_l + (int64_t)w_l -
+                         (int64_t)(16u * PZG_WAVE) * (int64_t)u_l;
+            bl_mod = (uint32_t)((uint64_t)bl % ADLER_MOD);
+        }
         uint32_t sum_a = wave_sum((uint32_t)(a_l % ADLER_MOD));
         uint32_t sum_b = wave_sum(bl_mod);
         // Adler32.hs:22-27 in block form: A' = A + sum d ; B' = B + n*A + sum (n - pos) d
@@ -663,11 +674,16 @@ struct Decoder {
     // Far sources lie below `flushed`, so inside the capacity while `flushed` is; a stream that has outgrown its capacity
     // is redone by the 32 KiB-ring kernel anyway (its far bytes were never stored): it reads its input instead.
     // Recomputed per flush (every KiB or so), not per segment.
+    // Round 3: far reads are plain (cached) loads -- 25 % fewer bytes fetched from beyond the L2 than with `nt`, same speed --
+    // which is safe because every line a far read touches is COMPLETE and final when it is read: a far source lies more than
+    // 1 KiB below `flushed` (op - flushed <= RING - 1024), only the line AT `flushed` can be partly written, output bytes
+    // are written once, and the idle lanes read FAR_IDLE (a whole line below `flushed`; the input before anything is
+    // flushed), never the line the next flush will write.  So no cache can hold a copy that a later store outdates.
     PZG_FN void set_far_base()
     {
         if (!HYBRID) return;
-        const bool ok = flushed < cap;
-        far_base = ok ? out + (flushed - 32768u) : in - 32768;
+        const bool ok = flushed < cap && flushed >= 128u;  // (below 2 KiB of output nothing is far anyway)
+        far_base = ok ? out + (flushed - 32768u) : in - FAR_IDLE;
         far_okmask = ok ? ~0ull : 0ull;
     }
 
@@ -1615,7 +1631,7 @@ struct Decoder {
     // ... the stores: at once for the lanes that have their byte; the far lanes' bytes are requested and left pending.
     // The far request is ONE unconditional load per pass, straight-line (a load inside a branch makes the compiler merge
     // its result with the old register -- a copy that waits for the load on the spot): base + 32-bit lane offset, lanes
-    // with no far source re-read a byte that is there anyway.
+    // with no far source read FAR_IDLE (see set_far_base: a byte that is there, in a line that is final).
     PZG_FN void segment_store(uint32_t o0, uint32_t run, uint32_t op32, const LaneVec<uint32_t> &VAL, const LaneVec<uint32_t> &DIST,
                               uint64_t farm, uint32_t fdelta, LaneVec<uint8_t> &pendF)
     {
@@ -1625,13 +1641,13 @@ struct Decoder {
         PZG_LANES_END
         if (HYBRID) {  // sources older than the ring: the stream's own flushed output (fdelta = op - flushed)
             PZG_LANES_BEGIN(j)
-                const uint32_t off = lane_bit(farm, j) ? 32768u + fdelta + (o0 + j) - PZG_LV(DIST, j) : 32768u;
-#if PZG_DEVICE_PASS && defined(PZG_FAR_NO_NT)   // experiment: far reads as plain (cached) loads
-                PZG_LV(pendF, j) = far_base[off];
-#elif PZG_DEVICE_PASS
+                const uint32_t off = lane_bit(farm, j) ? 32768u + fdelta + (o0 + j) - PZG_LV(DIST, j) : FAR_IDLE;
+#if PZG_DEVICE_PASS && defined(PZG_FAR_NT)   // (round 2's non-temporal far reads, for A/B)
                 PZG_LV(pendF, j) = __builtin_nontemporal_load(far_base + off);
+#elif PZG_DEVICE_PASS
+                PZG_LV(pendF, j) = far_base[off];
 #else
-                PZG_LV(pendF, j) = off != 32768u ? far_base[off] : (uint8_t)0;
+                PZG_LV(pendF, j) = off != FAR_IDLE ? far_base[off] : (uint8_t)0;
 #endif
             PZG_LANES_END
         }
