@@ -743,8 +743,9 @@ struct Decoder {
     // The byte `back` positions before the output cursor (1 <= back <= 32768, back <= op).
     // The LDS ring holds the last RING bytes.  With RING_BITS == 15 that is the whole DEFLATE window.
     // With a smaller ring (more resident stream-waves per CU) older bytes come from the stream's own
-    // output in HBM/L2: everything older than the ring has been flushed (op - flushed <= FLUSH_AT),
-    // flush_to() waits for its stores, and the load bypasses this CU's L1 (nt), so it sees them.
+    // output in HBM/L2: everything older than the ring has been flushed (op - flushed <= FLUSH_AT) and
+    // far_fence() waits for the flush's stores; the lines read are complete and final by then (set_far_base), so the
+    // segments' far loads are plain cached loads (this rare path keeps round 2's non-temporal ones).
     static constexpr bool HYBRID = RING_BITS < 15;
     PZG_FN uint8_t fetch_near(uint32_t back) const { return L.ring[((uint32_t)op - back) & RMASK]; }
     // Before far reads: every flush store of this wave must have landed.  By the time a byte is older
