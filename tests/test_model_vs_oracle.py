@@ -25,11 +25,13 @@ class R(C.Structure):
 @pytest.fixture(scope="session")
 def model():
     d = os.path.join(ROOT, "tests", "model")
-    so = os.path.join(d, "libpzgmodel.so")
+    # PZG_MODEL_FLAGS: extra -D options for the host model (e.g. -DPZG_PIPE_MIN_RING=11: every ring through hot_loop_pipe())
+    flags = os.environ.get("PZG_MODEL_FLAGS", "").split()
+    so = os.path.join(d, "libpzgmodel%s.so" % ("_" + hashlib.md5(" ".join(flags).encode()).hexdigest()[:8] if flags else ""))
     srcs = [os.path.join(d, "model_harness.cpp"), os.path.join(ROOT, "pure_zlib_amd", "csrc", "inflate_core.h"),
             os.path.join(ROOT, "pure_zlib_amd", "csrc", "wave.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", *flags, "-o", so, srcs[0]])
     M = C.CDLL(so)
     M.pzm_decompress.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(R)]
     M.pzm_decompress_gzip.argtypes = M.pzm_decompress.argtypes
@@ -194,7 +196,8 @@ class ModelDecoder:
 
 @pytest.fixture(scope="session")
 def model_lib(model):
-    M = C.CDLL(os.path.join(ROOT, "tests", "model", "libpzgmodel.so"))
+    flags = os.environ.get("PZG_MODEL_FLAGS", "").split()
+    M = C.CDLL(os.path.join(ROOT, "tests", "model", "libpzgmodel%s.so" % ("_" + hashlib.md5(" ".join(flags).encode()).hexdigest()[:8] if flags else "")))
     M.pzm_resume_state_bytes.restype = C.c_uint32
     M.pzm_resume_feed.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(R), C.POINTER(C.c_uint32)]
     M.pzm_decompress_dict.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(R)]
