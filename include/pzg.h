@@ -50,7 +50,7 @@ extern "C" {
 #endif
 
 #define PZG_VERSION_MAJOR 0
-#define PZG_VERSION_MINOR 2
+#define PZG_VERSION_MINOR 3
 
 /* ---- call-level return codes (the int every function returns) ---------------- */
 #define PZG_RC_OK            0

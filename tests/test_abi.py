@@ -74,7 +74,7 @@ def test_ring11_kernels_use_no_scratch():
 
 def test_version_and_strerror():
     L = _ffi.lib()
-    assert L.pzg_version() == 2  # (major << 16) | minor: 0.2
+    assert L.pzg_version() == 3  # (major << 16) | minor: 0.3 (round 3: reference-counted contexts, pzg_decompress_many_sharded)
     assert b"no CPU fallback" in L.pzg_strerror(_ffi.RC_NO_DEVICE)
 
 
