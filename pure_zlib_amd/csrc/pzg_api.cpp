@@ -1095,6 +1095,7 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
         std::lock_guard<std::mutex> g(dec->mu);
         const int num_cus = ctx->shards[0]->num_cus;
         HIP_TRY(ctx, hipSetDevice(dec->device));
+        (void)hipStreamSynchronize(dec->stream);  // (idle unless an earlier call left on an error: nothing of it may still use the staging)
         // Packed staging in page-locked memory.  One meta block, both ways:
         //   in_off | in_len | out_off | out_cap : u64[m]   (host -> device)
         //   out_len | in_used : u64[m]; state | adler | chunks : 32-bit [m]; detail u32[2m]   (device -> host)
