@@ -364,10 +364,14 @@ struct BitReader {
         rp = mis_bits;
         set_limits();
 #if PZG_DEVICE_PASS
+        // (the chunk indices pass through an opaque statement: as literal constants, lane + 64 and lane + 128 are computed once
+        // in the kernel's prologue and held in two vector registers for its whole life -- or spilled, in the gzip instance)
+        uint32_t c1 = 64u, c2 = 128u;
+        asm volatile("" : "+s"(c1), "+s"(c2));
         cur = load_chunk(0u);
-        nxt = load_chunk_raw(64u);  // masked when it becomes `cur`
+        nxt = load_chunk_raw(c1);  // masked when it becomes `cur`
 #if PZG_DMA_PREFETCH
-        dma_prefetch(128u);
+        dma_prefetch(c2);
 #endif
 #endif
     }
@@ -2257,7 +2261,13 @@ struct Decoder {
         set_far_base();
         br.start(in, in_len, 0);
         PZG_T0(tall);
-        if (in_len >> 34) fail(ST_TRUNCATED, 0, 0);  // the reader indexes dwords with 32 bits: 16 GiB per stream (include/pzg.h)
+        // the reader indexes dwords with 32 bits: 16 GiB per stream (include/pzg.h).  (Tested on the high word: a 64-bit
+        // compare is a vector instruction whose constant would sit in a vector-register pair for the whole kernel.)
+        uint32_t len_hi = (uint32_t)(in_len >> 32);
+#if PZG_DEVICE_PASS
+        asm volatile("" : "+s"(len_hi));  // (opaque: or the optimizer folds the test back into the 64-bit compare)
+#endif
+        if (len_hi >> 2) fail(ST_TRUNCATED, 0, 0);
         else decode();
         PZG_ACC(0, tall);
 #if PZG_DEVICE_PASS && PZG_DMA_PREFETCH

@@ -23,13 +23,11 @@ namespace pzg {
 #ifndef PZG_MIN_WAVES_11
 #define PZG_MIN_WAVES_11 7
 #endif
-// (there is no gzip instance of ring 11: it needs more vector registers than 7 or 6 waves per SIMD leave -- it spilled to
-// scratch -- and at 5 waves per SIMD it has the residency of ring 12, which reads less of its window from HBM: gzip
-// batches run the ring-12 instance, see launch_inflate)
+// (the gzip instance of ring 11 needs a few more vector registers than the zlib one: 80, six waves per SIMD, 24 stream-waves
+// per CU instead of 26 -- and nothing in scratch, which round 2's 72-register build of it had)
 constexpr int waves_per_simd(int ring_bits, bool gzip = false)
 {
-    (void)gzip;
-    return ring_bits <= 11 ? PZG_MIN_WAVES_11 : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
+    return ring_bits <= 11 ? (gzip ? 6 : PZG_MIN_WAVES_11) : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
 }
 template <int RING_BITS, bool GZIP = false>
 constexpr uint32_t waves_per_cu()
@@ -308,9 +306,9 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     hipError_t e = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back
     if (e != hipSuccess) return e;
     // Resident stream-waves per CU: 4 / 8 / 13 / 20 / 26 for rings 15 .. 11 (LDS-bound; ring 11: 72 VGPRs, 7 per SIMD by registers)
-    if (a.gzip && ring_bits == 11) ring_bits = 12;  // (no gzip instance of ring 11: see waves_per_simd)
     const uint32_t per_cu = ring_bits == 15 ? waves_per_cu<15>() : ring_bits == 14 ? waves_per_cu<14>()
-                            : ring_bits == 13 ? waves_per_cu<13>() : ring_bits == 12 ? waves_per_cu<12>() : waves_per_cu<11>();
+                            : ring_bits == 13 ? waves_per_cu<13>() : ring_bits == 12 ? waves_per_cu<12>()
+                            : a.gzip ? waves_per_cu<11, true>() : waves_per_cu<11>();
     uint32_t waves = (uint32_t)num_cus * per_cu;
     if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);  // experiment knob
     if (waves > a.n) waves = a.n;
@@ -334,7 +332,7 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     else if (ring_bits == 12)
         PZG_LAUNCH_RING(12);
     else if (ring_bits == 11)
-        hipLaunchKernelGGL((inflate_kernel<11, false, false>), grid, block, 0, stream, a);
+        PZG_LAUNCH_RING(11);
     else
         return hipErrorInvalidValue;
 #undef PZG_LAUNCH_RING

@@ -62,13 +62,13 @@ def test_ring11_kernels_use_no_scratch():
     kept under a budget so that it cannot creep up unnoticed."""
     kernels = _kernel_notes()
     ring11 = {n: k for n, k in kernels.items() if "inflate_kernelILi11E" in n}
-    assert len(ring11) == 1, sorted(kernels)  # (gzip batches run the ring-12 instance)
+    assert len(ring11) == 2, sorted(kernels)  # zlib and gzip
     for name, k in kernels.items():
         if "inflate_kernelILi1" in name:  # every ring size class, zlib and gzip, and the fixup instances
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
     for name, k in ring11.items():
         assert k["sgpr_spill_count"] <= 128, (name, k["sgpr_spill_count"])
-        assert k["vgpr_count"] <= 72, (name, k["vgpr_count"])  # 7 waves per SIMD by registers
+        assert k["vgpr_count"] <= (80 if "Lb0ELb1E" in name else 72), (name, k["vgpr_count"])  # gzip 6, zlib 7 waves per SIMD by registers
         assert k["group_segment_fixed_size"] <= 6144, name  # 26 stream-waves per CU
 
 
