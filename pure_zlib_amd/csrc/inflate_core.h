@@ -1713,8 +1713,12 @@ struct Decoder {
         PZG_MARK("e.scan");
         PZG_T0(t_b);
         // bytes of history a distance may reach back over; dist <= 32768, so a clamp is enough (scalar shift + test)
-        const uint32_t hist = (op >> 20) ? 0x100000u : (uint32_t)op + (RING_BITS == 15 ? hist_extra : 0u);
         const uint32_t op32 = (uint32_t)op;
+        uint32_t op_hi = (uint32_t)(op >> 32);
+#if PZG_DEVICE_PASS
+        asm("" : "+s"(op_hi));  // (opaque: `op >> 20` as written becomes a 64-bit VECTOR compare against a constant in a register pair)
+#endif
+        const uint32_t hist = (op_hi | (op32 >> 20)) ? 0x100000u : op32 + (RING_BITS == 15 ? hist_extra : 0u);
         LaneVec<uint32_t> INCL, START;
         LaneVec<bool> BIG, MATCH, SRC_IN, SRC_OUT;
         PZG_LANES_BEGIN(t)
