@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gzip", action="store_true", help="diagnostic: the same payloads as RFC 1952 members (extension; CRC-32 pass on the device)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-variants", action="store_true", help="skip the config 3 / config 5 share / 64 KiB legs of the default run")
     ap.add_argument("--incremental-decoders", type=int, default=4096, help="decoders of the incremental-path leg (pzg_decoder_feed, 32 KiB pieces); 0 = skip")
     args = ap.parse_args()
 
@@ -211,6 +212,20 @@ def main():
         elapsed = float(tt.item())
 
     # ---- verification: EVERY stream of the timed batch, bit-exact ---------------------------------
+    # The outputs are POISONED first and one more step -- the same call on the same arenas, outside the timed region -- is
+    # what gets verified: a step that did nothing cannot pass on what an earlier one left behind.  Its kernel time (HIP
+    # events) is reported beside the timed steps': the same work takes the same time.
+    verify_ms = None
+    if not args.no_verify:
+        d_out.fill_(0xCD)
+        d_status.fill_(-1)
+        d_out_len.zero_()
+        d_in_used.zero_()
+        d_adler.zero_()
+        torch.cuda.synchronize()
+        step()
+        verify_ms = ctx.last_kernel_ms()
+        torch.cuda.synchronize()
     status = d_status.cpu().numpy()
     out_len = d_out_len.cpu().numpy()
     adler = d_adler.cpu().numpy().view(np.uint32)
@@ -301,7 +316,8 @@ def main():
                 "ring_bits": ring_bits,
                 **({"container": "gzip members (extension): CRC-32 + ISIZE verified by a second kernel"} if args.gzip else {}),
                 "window": "32 KiB LDS ring" if ring_bits == 15 else f"{2**ring_bits // 1024} KiB LDS near ring + far back-references from the stream's flushed output (HBM/L2)",
-                "verified": "every stream: status, length, in_used, Adler-32 and full byte compare" if bit_exact is not None else "skipped",
+                "verified": ("every stream: status, length, in_used, Adler-32 and full byte compare, on one more step run after the "
+                             "timed region over POISONED output / status arrays") if bit_exact is not None else "skipped",
             },
             "roofline": {
                 "bound": "hbm",
@@ -314,12 +330,63 @@ def main():
                 "read_only_GBps": round(comp_total / (k_ms * 1e-3) / 1e9, 2),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": round(k_ms, 4),
+                "verified_step_kernel_ms": None if verify_ms is None else round(verify_ms, 4),
                 "traffic": traffic_from_profiles(args, ring_bits, n)[0],
                 "traffic_source": traffic_from_profiles(args, ring_bits, n)[1],
             },
         }
         if ab is not None:
             result["lds_ring_32k_variant"] = ab
+
+    # ---- BASELINE configs 3 and 5 and the 64 KiB batch of SURVEY.md 8d in the same run: one launch each over
+    # arenas resident in HBM, three timed launches (HIP events), every stream verified (status, length, in_used, Adler-32, every
+    # byte) on a run over poisoned outputs; each with its own algorithmic bytes and roofline fraction.
+    if rank == 0 and world == 1 and not args.no_variants and args.workload == "l6_32k":
+        from devbatch import DeviceBatch
+
+        def variant(name, what, texts_v, zs_v, count, seed):
+            pick_v = np.random.default_rng(seed).integers(0, len(zs_v), size=count)
+            vb = DeviceBatch(texts_v, zs_v, pick_v, dev=local_rank)
+            ok_v = True
+            try:
+                vb.check_all(*vb.run(ctx, ring_bits))  # (poisons the arenas first; raises on any difference)
+            except AssertionError as e:
+                ok_v = False
+                log(f"[bench] variant {name}: VERIFICATION FAILED {e}")
+            ms_v = []
+            for _ in range(3):
+                ctx.decompress_many_device(vb.d_in.data_ptr(), vb.d_in_off.data_ptr(), vb.d_in_len.data_ptr(), vb.d_out.data_ptr(),
+                                           vb.d_out_off.data_ptr(), vb.d_out_cap.data_ptr(), vb.d_out_len.data_ptr(), vb.d_status.data_ptr(),
+                                           vb.d_detail.data_ptr(), vb.d_in_used.data_ptr(), vb.d_adler.data_ptr(), vb.n, sync=True)
+                ms_v.append(ctx.last_kernel_ms())
+            dec_b, comp_b = int(vb.out_cap.sum()), int(vb.in_len.sum())
+            k = float(np.mean(ms_v))
+            result[name] = {"workload": what, "streams": int(vb.n), "distinct_blobs": len(zs_v), "kernel_ms": round(k, 3),
+                            "GiBps": round(dec_b / (k * 1e-3) / 2**30, 2), "compressed_GiBps": round(comp_b / (k * 1e-3) / 2**30, 2),
+                            "algorithmic_bytes_per_launch": dec_b + comp_b, "achieved_GBps": round((dec_b + comp_b) / (k * 1e-3) / 1e9, 2),
+                            "frac": round((dec_b + comp_b) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bit_exact": ok_v,
+                            "verified": "every stream: status, length, in_used, Adler-32, every byte (poisoned arenas)"}
+            del vb
+            torch.cuda.empty_cache()
+            return ok_v
+
+        npv = min(args.pool, 1024)
+        tv = [corpus.zipf_text(4096, s_) for s_ in range(npv)]
+        zv = []
+        for t_ in tv:
+            co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+            zv.append(co.compress(t_) + co.flush())
+        v_ok = variant("fixed_4k_variant", "BASELINE config 3: 65,536 x 4 KiB fixed-Huffman (Z_FIXED level-1) blobs", tv, zv, 65536, 0xC3)
+        tv = [corpus.zipf_text(1024 * (1 + (s_ * 2654435761 >> 7) % 64), s_) for s_ in range(npv)]
+        zv = [zlib.compress(t_, 6) for t_ in tv]
+        v_ok &= variant("mixed_share_variant", "BASELINE config 5's per-GPU share: 131,072 mixed 1-64 KiB level-6 blobs (1 M over 8 GPUs)",
+                        tv, zv, 131072, 0xC5)
+        tv = [corpus.zipf_text(65536, 5000 + s_) for s_ in range(npv)]
+        zv = [zlib.compress(t_, 6) for t_ in tv]
+        v_ok &= variant("blob_64k_variant", "SURVEY.md 8d: 32,768 x 64 KiB level-6 blobs (same code path, ring wrap)", tv, zv, 32768, 0xC6)
+        if not v_ok:
+            bit_exact = False
+            result["bit_exact"] = False
 
     # ---- the same batch handed over as HOST buffers (what a `decompress` caller pays): staging + H2D + kernel + D2H.
     # Reported beside `value`, never as `value` (which is measured with the arenas resident in HBM).
@@ -338,6 +405,29 @@ def main():
                     "pinned staging + PCIe both ways + kernel, one call",
         }
         del h_out
+        # ... and as PAGE-LOCKED arenas (pzg_host_alloc + PZG_HOST_PINNED: what the module mirrors hand over): the copy engines
+        # read and write the caller's memory, nothing is packed or copied out
+        try:
+            from pure_zlib_amd.zlib import PinnedArena
+            p_in, p_out = PinnedArena(h_in.size), PinnedArena(int(d_out.numel()))
+            p_in.a[:] = h_in
+            ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)  # warm the device mirrors
+            p_out.a[:] = 0xCD
+            t0h = time.perf_counter()
+            o_len, o_st, _det, _used, o_ad = ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
+            dtp = time.perf_counter() - t0h
+            ok_p = bool((o_st == 0).all() and (o_len == out_cap).all() and (o_ad == exp_adler).all()) if not args.no_verify else None
+            if ok_p:
+                for k0 in (0, n // 2, n - 1):
+                    ok_p = ok_p and p_out.a[int(out_off[k0]):int(out_off[k0]) + int(out_cap[k0])].tobytes() == texts[pick[k0]]
+            result["host_buffers_variant"]["pinned"] = {
+                "GiBps": round(int(out_cap.sum()) / dtp / 2**30, 2), "ms": round(dtp * 1e3, 1), "ok": ok_p,
+                "note": "the same batch in page-locked arenas (pzg_host_alloc) with PZG_HOST_PINNED: PCIe both ways + kernel, no staging copy",
+            }
+            p_in.close()
+            p_out.close()
+        except MemoryError as e:
+            result["host_buffers_variant"]["pinned"] = {"skipped": str(e)}
 
     # ---- the incremental path (Benchmark.hs:53-70): 4,096 resumable decoders fed 32 KiB pieces,
     # host buffers both ways, one launch per feed call.  Reported beside `value`, never as it.

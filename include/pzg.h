@@ -50,7 +50,7 @@ extern "C" {
 #endif
 
 #define PZG_VERSION_MAJOR 0
-#define PZG_VERSION_MINOR 3
+#define PZG_VERSION_MINOR 4
 
 /* ---- call-level return codes (the int every function returns) ---------------- */
 #define PZG_RC_OK            0
@@ -89,6 +89,15 @@ extern "C" {
 /* pzg_decompress_many_dict only (extension): */
 #define PZG_E_DICT               20  /* "Header error: preset dictionary mismatch: <hex d0> != <hex d1>": the stream's DICTID (d0) is
                                       * not the Adler-32 of the dictionary supplied for it (d1) */
+/* Reference raise sites that have NO status because they cannot fire (here or in the reference):
+ *   Deflate.hs:150-151  DecompressionError "Unexpected code: <n>" -- getCodeLengths' fall-through for a code-length symbol outside
+ *                       0..18; the code-length alphabet has exactly 19 symbols (Deflate.hs:87-88 builds its tree from 19 lengths),
+ *                       so nextCode can only return 0..18.
+ *   HuffmanTree.hs:77   HuffmanTreeError "Tried to advance value!" -- advanceTree on a leaf; nextCode (Monad.hs:295-302) restarts
+ *                       from the root as soon as advanceTree returns a value, so a leaf is never advanced.
+ *   Monad.hs:277        FormatError "Can't get a block on a non-byte boundary." -- nextBlock with bits pending; its only caller
+ *                       (Deflate.hs:70-72) runs advanceToByte first.
+ * The oracle keeps the first two as dead code for fidelity; no input reaches them. */
 /* pzg_decoder_feed only: a decoder that is not finished */
 #define PZG_DEC_NEED_INPUT      101  /* NeedMore (Monad.hs:164): every complete element of the input has been decoded */
 #define PZG_DEC_OUT_FULL        102  /* this call's output room is used up: call again with the rest of the input */
@@ -105,6 +114,15 @@ extern "C" {
                               * one RFC 1952 member (gzip header, deflate, CRC-32 + ISIZE); adler[] then holds the CRC-32 */
 #define PZG_LPT_ORDER    8u  /* device-pointer batches of mixed sizes: launch the longest streams (largest out_cap[]) first; the
                               * permutation is built on the device.  Host-pointer batches are always launched that way. */
+#define PZG_HOST_PINNED 16u  /* host-pointer batches whose in_base / out_base arenas are PAGE-LOCKED (pzg_host_alloc, or hipHostMalloc /
+                              * hipHostRegister by the caller): the copy engines read and write them directly -- no packing into
+                              * staging, no copy-out; this is the path the module mirrors (`decompress` / `decompressMany`) take.
+                              * Requirements: extents in ascending order on both sides (in_off[i] + in_len[i] <= in_off[i+1], the same for
+                              * out_off / out_cap; PZG_RC_BAD_ARG otherwise); the whole span of the output arena from the first extent
+                              * to the end of the last is written (bytes in gaps BETWEEN extents are unspecified afterwards, bytes
+                              * outside the span are untouched); gaps of the input arena travel over the link, so pack tightly
+                              * (16-byte aligned extents keep the wide store path).  Pageable memory under this flag is still
+                              * correct, only slower.  Not combined with preset dictionaries. */
 
 typedef struct pzg_ctx pzg_ctx;
 
@@ -118,6 +136,11 @@ PZG_API int  pzg_init(int device, pzg_ctx **out);
  * are independent, so nothing crosses between devices (no collective).  PZG_DEVICE_PTRS calls of pzg_decompress_many need a
  * one-device context; data that already lives on several devices goes through pzg_decompress_many_sharded(). */
 PZG_API int  pzg_init_mask(uint32_t device_mask, pzg_ctx **out);
+/* The same with the devices named one by one: one shard per entry, in that order (shard k of
+ * pzg_decompress_many_sharded = devices[k]).  A device may be named more than once -- several shards then share it, each
+ * with its own streams, arenas and host thread (a way to keep more batches in flight on one device, and how the
+ * multi-shard code is exercised on a one-GPU box). */
+PZG_API int  pzg_init_devices(const int32_t *devices, uint32_t ndevices, pzg_ctx **out);
 PZG_API int  pzg_device_count(pzg_ctx *ctx);  /* devices (shards) of the context */
 /* Drop the caller's reference (see "Lifetimes" above): synchronises, invalidates the handle, frees everything unless
  * decoders are still alive -- then the last pzg_decoder_destroy() frees it.  NULL is ignored. */
@@ -138,7 +161,17 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
  *   Results are bit-identical for every value.  Default: PZG_DEFAULT_RING_BITS. */
 #define PZG_OPT_RING_BITS 1
 #define PZG_DEFAULT_RING_BITS 11
+/* PZG_OPT_HOST_THREADS: helper threads (1..256) that pack / copy out the STAGED host-pointer path and the decoders' feeds
+ *   (default: the machine's hardware threads, at most 24).  Set it while no host-pointer call is running. */
+#define PZG_OPT_HOST_THREADS 2
 PZG_API int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
+/* The only environment variable the library reads is PZG_RING_BITS (11..15): the default of PZG_OPT_RING_BITS for
+ * contexts created afterwards. */
+
+/* Page-locked host memory for PZG_HOST_PINNED arenas (hipHostMalloc, portable across the node's devices).  NULL when the
+ * system will not lock that much.  Free with pzg_host_free (NULL is ignored).  No context is needed. */
+PZG_API void *pzg_host_alloc(size_t bytes);
+PZG_API void  pzg_host_free(void *p);
 
 /*
  * decompressMany: decode n independent zlib (RFC 1950) streams, one wavefront per stream.
@@ -222,6 +255,10 @@ PZG_API int pzg_decompress_many_dict(pzg_ctx *ctx,
  *                (OutputWindow.hs:45-54); the host mirror cuts the delivered bytes into exactly those Chunks, and at
  *                PZG_OK publishes the remainder as the last one (finalize, Monad.hs:349-353).
  * Host pointers only.  Nothing is re-decoded: a feed costs what its new input costs.
+ * Footprint: a pzg_decoder keeps, grow-only until pzg_decoder_destroy, staging of the largest feed it has seen --
+ * m x (in_len + 32) + m x out_cap bytes of page-locked host memory and as much device memory -- plus ~37 KiB of device
+ * state per decoder.  Where the system will not lock that much the staging falls back to pageable memory (slower copies,
+ * same results).
  */
 typedef struct pzg_decoder pzg_decoder;
 PZG_API int  pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out);  /* takes a reference on ctx */

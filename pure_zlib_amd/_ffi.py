@@ -37,12 +37,14 @@ DEVICE_PTRS = 1
 ASYNC = 2
 GZIP = 4  # extension: streams are RFC 1952 members; adler[] holds the CRC-32
 LPT_ORDER = 8  # device-pointer batches: launch the longest streams first
+HOST_PINNED = 16  # host-pointer batches in page-locked arenas (pzg_host_alloc), extents ascending: no staging, no copy-out
 OPT_RING_BITS = 1
+OPT_HOST_THREADS = 2
 DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares
 SYMBOLS = [
-    "pzg_init", "pzg_init_mask", "pzg_device_count", "pzg_adler32_many", "pzg_decompress_many_dict", "pzg_decompress_many_sharded",
+    "pzg_init", "pzg_init_mask", "pzg_init_devices", "pzg_host_alloc", "pzg_host_free", "pzg_device_count", "pzg_adler32_many", "pzg_decompress_many_dict", "pzg_decompress_many_sharded",
     "pzg_decoder_create", "pzg_decoder_destroy", "pzg_decoder_reset", "pzg_decoder_feed", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
     "pzg_adler32", "pzg_error_message", "pzg_last_kernel_ms", "pzg_strerror", "pzg_last_error", "pzg_version",
 ]
@@ -78,6 +80,12 @@ def lib():
     L.pzg_init.restype = C.c_int
     L.pzg_init_mask.argtypes = [C.c_uint32, C.POINTER(C.c_void_p)]
     L.pzg_init_mask.restype = C.c_int
+    L.pzg_init_devices.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.pzg_init_devices.restype = C.c_int
+    L.pzg_host_alloc.argtypes = [C.c_size_t]
+    L.pzg_host_alloc.restype = C.c_void_p
+    L.pzg_host_free.argtypes = [C.c_void_p]
+    L.pzg_host_free.restype = None
     L.pzg_device_count.argtypes = [C.c_void_p]
     L.pzg_device_count.restype = C.c_int
     L.pzg_adler32_many.argtypes = [C.c_void_p, vp, u64p, u64p, u32p, C.c_uint32, C.c_uint32]

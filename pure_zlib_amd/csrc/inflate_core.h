@@ -756,7 +756,7 @@ struct Decoder {
     // than the ring its flush is long complete, so this wait is normally free.
     PZG_FN void far_fence() const
     {
-#if PZG_DEVICE_PASS && !defined(PZG_NO_FAR_FENCE)
+#if PZG_DEVICE_PASS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
@@ -988,9 +988,6 @@ struct Decoder {
             if (TREE == TREE_LITLEN) {
                 lit_sub_used = sub_total;
                 use_sub = np_fit >= SUB_MIN_PREFIXES ? 1u : 0u;
-#if defined(PZG_NO_SUB)
-                use_sub = 0u;  // (experiment: the one-level window code only)
-#endif
             }
 #pragma nounroll
             for (uint32_t i0 = 0; i0 < sub_total; i0 += PZG_WAVE) {
@@ -1647,9 +1644,7 @@ struct Decoder {
         if (HYBRID) {  // sources older than the ring: the stream's own flushed output (fdelta = op - flushed)
             PZG_LANES_BEGIN(j)
                 const uint32_t off = lane_bit(farm, j) ? 32768u + fdelta + (o0 + j) - PZG_LV(DIST, j) : FAR_IDLE;
-#if PZG_DEVICE_PASS && defined(PZG_FAR_NT)   // (round 2's non-temporal far reads, for A/B)
-                PZG_LV(pendF, j) = __builtin_nontemporal_load(far_base + off);
-#elif PZG_DEVICE_PASS
+#if PZG_DEVICE_PASS
                 PZG_LV(pendF, j) = far_base[off];
 #else
                 PZG_LV(pendF, j) = off != FAR_IDLE ? far_base[off] : (uint8_t)0;
@@ -1890,24 +1885,6 @@ struct Decoder {
                 }
                 LaneVec<uint32_t> TB0, TB1;
                 window2_decode<FX>(TB0, TK0, TB1, TK1);
-#if PZG_DEVICE_PASS && defined(PZG_EXP_NOP)   // cost-model experiments (never in the product build): per window,
-                asm volatile(".rept " PZG_STR(PZG_EXP_NOP) "\n\ts_nop 0\n\t.endr");                 // 4-byte no-ops
-#endif
-#if PZG_DEVICE_PASS && defined(PZG_EXP_VALU4)
-                { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU4) "\n\tv_mov_b32_e32 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 4-byte vector
-#endif
-#if PZG_DEVICE_PASS && defined(PZG_EXP_VALU8)
-                { uint32_t x = TB0.v; asm volatile(".rept " PZG_STR(PZG_EXP_VALU8) "\n\tv_mov_b32_e64 %0, %0\n\t.endr" : "+v"(x)); TB0.v = x; }  // 8-byte vector
-#endif
-#if PZG_DEVICE_PASS && defined(PZG_EXP_VALU_IND)   // ... independent of one another (four destinations, one source)
-                { uint32_t x = TB0.v, t0, t1, t2, t3; asm volatile(".rept " PZG_STR(PZG_EXP_VALU_IND) "\n\tv_mov_b32_e32 %0, %4\n\tv_mov_b32_e32 %1, %4\n\tv_mov_b32_e32 %2, %4\n\tv_mov_b32_e32 %3, %4\n\t.endr" : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(x)); }
-#endif
-#if PZG_DEVICE_PASS && defined(PZG_EXP_SALU_IND)
-                { uint32_t x = qn, t0, t1, t2, t3; asm volatile(".rept " PZG_STR(PZG_EXP_SALU_IND) "\n\ts_mov_b32 %0, %4\n\ts_mov_b32 %1, %4\n\ts_mov_b32 %2, %4\n\ts_mov_b32 %3, %4\n\t.endr" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(x)); }
-#endif
-#if PZG_DEVICE_PASS && defined(PZG_EXP_SALU4)
-                { uint32_t x = qn; asm volatile(".rept " PZG_STR(PZG_EXP_SALU4) "\n\ts_mov_b32 %0, %0\n\t.endr" : "+s"(x)); qn = x; }  // 4-byte scalar
-#endif
                 S0 = 0;
                 S1 = 0;
                 k1 = 0;

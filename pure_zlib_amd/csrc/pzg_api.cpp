@@ -43,6 +43,7 @@ struct Arena {
 struct Pinned {
     uint8_t *p = nullptr;
     size_t cap = 0;
+    bool pageable = false;  // hipHostMalloc refused (locked-memory limit): plain malloc, the copies then go the runtime's slower way
 };
 
 constexpr uint32_t ADLER_MAX_WAVES = 8192;  // 256 CUs x 32 waves
@@ -86,7 +87,8 @@ constexpr int NSLOT = 3;  // ranges in flight per lane: one being packed / uploa
 struct Lane {
     hipStream_t s_k = nullptr, s_up = nullptr, s_dn = nullptr;
     hipEvent_t ev_up[NSLOT] = {}, ev_k[NSLOT] = {}, ev_dn[NSLOT] = {};
-    Arena d_in[NSLOT], d_out[NSLOT], d_meta[NSLOT], d_gz[NSLOT];
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // first / last kernel of the call this lane is running (pzg_last_kernel_ms)
+    Arena d_in[NSLOT], d_out[NSLOT], d_meta[NSLOT], d_gz[NSLOT], d_ord[NSLOT];
     Pinned h_in[NSLOT], h_out[NSLOT], h_meta[NSLOT];
     uint32_t *d_counter = nullptr;
     std::mutex mu;
@@ -98,11 +100,17 @@ struct Shard {
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // the device-pointer path launches here (pzg_set_stream)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the last device-pointer launch (recorded under `mu`, so always a pair)
     bool timed = false;
-    uint32_t *d_counters = nullptr;  // COUNTER_SLOTS x 2 words
+    double host_ms = -1.0;           // kernel span of the last host-pointer call that finished (measured by that call itself)
+    bool last_was_host = false;
+    // Per-launch resources of the device-pointer path: launches on different user streams (pzg_set_stream in between,
+    // PZG_ASYNC) may overlap, so each takes the next of COUNTER_SLOTS slots -- its own work counter, launch permutation
+    // and expected-CRC array.  A slot comes round again after COUNTER_SLOTS launches.
+    uint32_t *d_counters = nullptr;  // COUNTER_SLOTS x 64 words
     std::atomic<uint32_t> next_counter{0};
-    Arena a_adler, a_scratch, a_gz, a_order, a_dec;
+    Arena a_adler, a_scratch, a_dec;
+    Arena a_gz[COUNTER_SLOTS], a_order[COUNTER_SLOTS];
     Lane lanes[LANES_PER_SHARD];
     std::atomic<uint32_t> next_lane{0};
     std::mutex mu;  // device-pointer path bookkeeping (stream pointer, arenas above, timing events)
@@ -159,17 +167,34 @@ int arena_reserve(pzg_ctx *ctx, Arena &a, size_t bytes)
     return PZG_RC_OK;
 }
 
+void pinned_release(Pinned &a)
+{
+    if (a.p) {
+        if (a.pageable) free(a.p);
+        else (void)hipHostFree(a.p);
+    }
+    a.p = nullptr;
+    a.cap = 0;
+    a.pageable = false;
+}
+
+// Staging in page-locked memory (the copies then run at link speed and really are asynchronous).  Where the system
+// will not lock that much (ulimit -l, cgroup), pageable memory does the same job slower: a large batch of decoders or
+// streams must not fail for want of LOCKED memory when the memory itself is there.
 int pinned_reserve(pzg_ctx *ctx, Pinned &a, size_t bytes)
 {
     bytes = (bytes + 4095u) & ~(size_t)4095u;
     if (a.cap >= bytes) return PZG_RC_OK;
-    if (a.p) HIP_TRY(ctx, hipHostFree(a.p));
-    a.p = nullptr;
-    a.cap = 0;
+    pinned_release(a);
     hipError_t e = hipHostMalloc((void **)&a.p, bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
-        hip_fail(ctx, e, "hipHostMalloc");
-        return PZG_RC_NO_MEMORY;
+        (void)hipGetLastError();
+        a.p = (uint8_t *)malloc(bytes);
+        if (!a.p) {
+            hip_fail(ctx, e, "hipHostMalloc");
+            return PZG_RC_NO_MEMORY;
+        }
+        a.pageable = true;
     }
     a.cap = bytes;
     return PZG_RC_OK;
@@ -186,6 +211,8 @@ int lane_prepare(pzg_ctx *ctx, Lane &ln)
         HIP_TRY(ctx, hipEventCreateWithFlags(&ln.ev_k[c], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ln.ev_dn[c], hipEventDisableTiming));
     }
+    HIP_TRY(ctx, hipEventCreate(&ln.ev_t0));
+    HIP_TRY(ctx, hipEventCreate(&ln.ev_t1));
     if (hipMalloc((void **)&ln.d_counter, 256) != hipSuccess) return PZG_RC_NO_MEMORY;
     ln.ready = true;
     return PZG_RC_OK;
@@ -194,14 +221,15 @@ int lane_prepare(pzg_ctx *ctx, Lane &ln)
 void lane_destroy(Lane &ln)
 {
     for (int c = 0; c < NSLOT; ++c) {
-        for (Arena *a : {&ln.d_in[c], &ln.d_out[c], &ln.d_meta[c], &ln.d_gz[c]})
+        for (Arena *a : {&ln.d_in[c], &ln.d_out[c], &ln.d_meta[c], &ln.d_gz[c], &ln.d_ord[c]})
             if (a->p) (void)hipFree(a->p);
-        for (Pinned *p : {&ln.h_in[c], &ln.h_out[c], &ln.h_meta[c]})
-            if (p->p) (void)hipHostFree(p->p);
+        for (Pinned *p : {&ln.h_in[c], &ln.h_out[c], &ln.h_meta[c]}) pinned_release(*p);
         if (ln.ev_up[c]) (void)hipEventDestroy(ln.ev_up[c]);
         if (ln.ev_k[c]) (void)hipEventDestroy(ln.ev_k[c]);
         if (ln.ev_dn[c]) (void)hipEventDestroy(ln.ev_dn[c]);
     }
+    if (ln.ev_t0) (void)hipEventDestroy(ln.ev_t0);
+    if (ln.ev_t1) (void)hipEventDestroy(ln.ev_t1);
     if (ln.d_counter) (void)hipFree(ln.d_counter);
     if (ln.s_k) (void)hipStreamDestroy(ln.s_k);
     if (ln.s_up) (void)hipStreamDestroy(ln.s_up);
@@ -238,8 +266,11 @@ void shard_destroy(Shard &sh)
     (void)hipSetDevice(sh.device);
     (void)hipDeviceSynchronize();
     for (Lane &ln : sh.lanes) lane_destroy(ln);
-    for (Arena *a : {&sh.a_adler, &sh.a_scratch, &sh.a_gz, &sh.a_order, &sh.a_dec})
+    for (Arena *a : {&sh.a_adler, &sh.a_scratch, &sh.a_dec})
         if (a->p) (void)hipFree(a->p);
+    for (int k = 0; k < COUNTER_SLOTS; ++k)
+        for (Arena *a : {&sh.a_gz[k], &sh.a_order[k]})
+            if (a->p) (void)hipFree(a->p);
     if (sh.d_counters) (void)hipFree(sh.d_counters);
     if (sh.ev0) (void)hipEventDestroy(sh.ev0);
     if (sh.ev1) (void)hipEventDestroy(sh.ev1);
@@ -265,9 +296,8 @@ int ctx_create(const std::vector<int> &devices, pzg_ctx **out)
         const int rb = atoi(e);
         if (rb >= 11 && rb <= 15) ctx->ring_bits = rb;
     }
-    unsigned hw = std::thread::hardware_concurrency();
-    if (const char *e = getenv("PZG_HOST_THREADS")) hw = (unsigned)atoi(e);
-    ctx->helpers.reset(new Helpers(hw > 24u ? 24u : hw < 1u ? 1u : hw));
+    const unsigned hw = std::thread::hardware_concurrency();
+    ctx->helpers.reset(new Helpers(hw > 24u ? 24u : hw < 1u ? 1u : hw));  // (PZG_OPT_HOST_THREADS changes it)
     *out = ctx;
     return PZG_RC_OK;
 }
@@ -288,16 +318,18 @@ int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
     HIP_TRY(ctx, hipSetDevice(sh.device));
     const uint32_t slot = sh.next_counter.fetch_add(1u) % COUNTER_SLOTS;  // its own counter: launches on different streams may overlap
     a.counter = sh.d_counters + 64u * slot;
+    // (arena_reserve only ever frees a slot's old array through hipFree, which waits for the device: a launch still
+    // reading it has finished by then)
     if (flags & PZG_GZIP) {
-        int rc = arena_reserve(ctx, sh.a_gz, 8 * (size_t)a.n);
+        int rc = arena_reserve(ctx, sh.a_gz[slot], 8 * (size_t)a.n);
         if (rc != PZG_RC_OK) return rc;
         a.gzip = 1;
-        a.gz_expect = (uint32_t *)sh.a_gz.p;
+        a.gz_expect = (uint32_t *)sh.a_gz[slot].p;
     }
     if (flags & PZG_LPT_ORDER) {  // longest streams first: a launch permutation built on the device from out_cap[]
-        int rc = arena_reserve(ctx, sh.a_order, 4 * (size_t)a.n + 1024);
+        int rc = arena_reserve(ctx, sh.a_order[slot], 4 * (size_t)a.n + 1024);
         if (rc != PZG_RC_OK) return rc;
-        uint32_t *ord = (uint32_t *)sh.a_order.p;
+        uint32_t *ord = (uint32_t *)sh.a_order[slot].p;
         HIP_TRY(ctx, pzg::launch_order(a.out_cap, a.n, ord + 256, ord, sh.stream));
         a.order = ord + 256;
     }
@@ -308,6 +340,7 @@ int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
     HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, sh.stream));
     HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
     sh.timed = true;
+    sh.last_was_host = false;
     if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(sh.stream));
     return PZG_RC_OK;
 }
@@ -328,15 +361,25 @@ struct HostBatch {
 
 struct Range {
     uint32_t lo, hi;          // positions in idx[]
-    size_t in_bytes, out_bytes;  // packed sizes
+    size_t in_bytes, out_bytes;  // packed sizes (PZG_HOST_PINNED: the spans of the caller's arenas the range covers)
+    uint64_t in_lo = 0, out_lo = 0;  // PZG_HOST_PINNED: where those spans start in the caller's arenas
+    bool mixed = false;       // PZG_HOST_PINNED: capacities differ inside the range (launched longest first by a device-side permutation)
 };
 
 inline size_t pad16(size_t x) { return (x + 15u) & ~(size_t)15u; }
 inline size_t pad256(size_t x) { return (x + 255u) & ~(size_t)255u; }
 
+// The host-pointer path.  Two forms:
+//   staged (default)    pageable caller memory: the streams are packed into page-locked staging (no gaps travel), launched
+//                       longest first, and the decoded bytes come back through page-locked staging and are copied out;
+//   PZG_HOST_PINNED     the caller's arenas are page-locked (pzg_host_alloc) and laid out in ascending order: the copy
+//                       engines read and write them directly -- no packing, no staging, no copy-out.  The device holds a
+//                       mirror of the spans the batch covers; a range uploads its span of the input arena and downloads its
+//                       span of the output arena (gaps between extents travel along).
 int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, uint32_t m)
 {
     if (m == 0) return PZG_RC_OK;
+    const bool pinned = (b.flags & PZG_HOST_PINNED) != 0;
     // the first free lane of this shard in a fixed order (a lone caller always lands on the same, warm one); if all
     // are taken, queue on one of them
     Lane *lane = nullptr;
@@ -356,18 +399,31 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
     HIP_TRY(ctx, hipSetDevice(sh.device));
     int rc = lane_prepare(ctx, ln);
     if (rc != PZG_RC_OK) return rc;
+#if defined(PZG_LAB)
     const bool trace = getenv("PZG_TRACE_HOST") != nullptr;
+#else
+    const bool trace = false;
+#endif
     const auto t_call0 = std::chrono::steady_clock::now();
 
     // ranges of the (already ordered) stream list: a few per call, each below RANGE_MAX_OUT of packed output
     size_t tot_in = 0, tot_out = 0;
-    for (uint32_t k = 0; k < m; ++k) {
-        tot_in += pad16(b.in_len[idx[k]]);
-        tot_out += pad16(b.out_cap[idx[k]]);
+    uint64_t g_in_lo = 0, g_out_lo = 0;  // PZG_HOST_PINNED: the batch's spans start here (extents ascend: validated by the caller)
+    if (pinned) {
+        g_in_lo = b.in_off[idx[0]];
+        g_out_lo = b.out_off[idx[0]];
+        tot_in = (size_t)(b.in_off[idx[m - 1]] + b.in_len[idx[m - 1]] - g_in_lo);
+        tot_out = (size_t)(b.out_off[idx[m - 1]] + b.out_cap[idx[m - 1]] - g_out_lo);
+    } else {
+        for (uint32_t k = 0; k < m; ++k) {
+            tot_in += pad16(b.in_len[idx[k]]);
+            tot_out += pad16(b.out_cap[idx[k]]);
+        }
     }
     size_t target_out = tot_out / 6 + 1, target_in = tot_in / 6 + 1;
     if (tot_in + tot_out < (96ull << 20) || m < 2048u) target_out = target_in = ~(size_t)0 >> 1;  // small batch: one range
-    if (target_out > RANGE_MAX_OUT) target_out = RANGE_MAX_OUT;
+    if (!pinned && target_out > RANGE_MAX_OUT) target_out = RANGE_MAX_OUT;
+#if defined(PZG_LAB)
     if (const char *e = getenv("PZG_HOST_RANGES")) {  // experiment knob
         const int v = atoi(e);
         if (v >= 1) {
@@ -375,6 +431,7 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
             target_in = tot_in / (size_t)v + 1;
         }
     }
+#endif
     std::vector<Range> rg;
     {
         Range r{0, 0, 0, 0};
@@ -390,6 +447,16 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         }
         rg.push_back(r);
     }
+    if (pinned) {
+        for (Range &r : rg) {
+            const uint32_t f = idx[r.lo], l = idx[r.hi - 1];
+            r.in_lo = b.in_off[f];
+            r.out_lo = b.out_off[f];
+            r.in_bytes = (size_t)(b.in_off[l] + b.in_len[l] - r.in_lo);
+            r.out_bytes = (size_t)(b.out_off[l] + b.out_cap[l] - r.out_lo);
+            for (uint32_t k = r.lo + 1; k < r.hi && !r.mixed; ++k) r.mixed = b.out_cap[idx[k]] != b.out_cap[f];
+        }
+    }
     size_t max_in = 0, max_out = 0, max_n = 0;
     for (const Range &r : rg) {
         max_in = std::max(max_in, r.in_bytes);
@@ -399,16 +466,24 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
     // per-range meta block (u64[n] x 6 | i32 status | u32 adler | u32 detail[2n]), identical on host and device
     const size_t meta_bytes = 64 * max_n;
     const int nslot = (int)std::min<size_t>(rg.size(), (size_t)NSLOT);
+    if (pinned) {  // one mirror of each arena's span for the whole call
+        if ((rc = arena_reserve(ctx, ln.d_in[0], tot_in + 64)) != PZG_RC_OK) return rc;
+        if ((rc = arena_reserve(ctx, ln.d_out[0], tot_out + 64)) != PZG_RC_OK) return rc;
+    }
     for (int s = 0; s < nslot; ++s) {
-        if ((rc = arena_reserve(ctx, ln.d_in[s], max_in + 64)) != PZG_RC_OK) return rc;
-        if ((rc = arena_reserve(ctx, ln.d_out[s], max_out + 64)) != PZG_RC_OK) return rc;
+        if (!pinned) {
+            if ((rc = arena_reserve(ctx, ln.d_in[s], max_in + 64)) != PZG_RC_OK) return rc;
+            if ((rc = arena_reserve(ctx, ln.d_out[s], max_out + 64)) != PZG_RC_OK) return rc;
+            if ((rc = pinned_reserve(ctx, ln.h_in[s], max_in + 64)) != PZG_RC_OK) return rc;
+            if ((rc = pinned_reserve(ctx, ln.h_out[s], max_out + 64)) != PZG_RC_OK) return rc;
+        } else if ((rc = arena_reserve(ctx, ln.d_ord[s], 4 * max_n + 1024)) != PZG_RC_OK) {
+            return rc;
+        }
         if ((rc = arena_reserve(ctx, ln.d_meta[s], meta_bytes + 64)) != PZG_RC_OK) return rc;
         if ((b.flags & PZG_GZIP) && (rc = arena_reserve(ctx, ln.d_gz[s], 8 * max_n + 64)) != PZG_RC_OK) return rc;
-        if ((rc = pinned_reserve(ctx, ln.h_in[s], max_in + 64)) != PZG_RC_OK) return rc;
-        if ((rc = pinned_reserve(ctx, ln.h_out[s], max_out + 64)) != PZG_RC_OK) return rc;
         if ((rc = pinned_reserve(ctx, ln.h_meta[s], meta_bytes + 64)) != PZG_RC_OK) return rc;
     }
-    const unsigned helpers = (tot_in + tot_out) >= (32ull << 20) ? ctx->helpers->size() : 1u;
+    const unsigned helpers = (!pinned && (tot_in + tot_out) >= (32ull << 20)) ? ctx->helpers->size() : 1u;
 
     auto meta_ptrs = [&](uint8_t *base, size_t nn, uint64_t *&ioff, uint64_t *&ilen, uint64_t *&ooff, uint64_t *&ocap, uint64_t *&olen,
                          uint64_t *&used, int32_t *&st, uint32_t *&ad, uint32_t *&det) {
@@ -423,13 +498,23 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         det = ad + nn;
     };
 
-    // pack the range's streams into its pinned input slot and lay out its extents
+    // lay out the range's extents; staged: pack its streams into the pinned input slot
     auto pack = [&](const Range &r, int s) {
         const size_t nn = r.hi - r.lo;
         uint64_t *ioff, *ilen, *ooff, *ocap, *olen, *used;
         int32_t *st;
         uint32_t *ad, *det;
         meta_ptrs(ln.h_meta[s].p, nn, ioff, ilen, ooff, ocap, olen, used, st, ad, det);
+        if (pinned) {  // the caller's own layout, relative to the start of the batch's spans
+            for (size_t q = 0; q < nn; ++q) {
+                const uint32_t i = idx[r.lo + q];
+                ioff[q] = b.in_off[i] - g_in_lo;
+                ilen[q] = b.in_len[i];
+                ooff[q] = b.out_off[i] - g_out_lo;
+                ocap[q] = b.out_cap[i];
+            }
+            return;
+        }
         size_t ip = 0, op = 0;
         for (size_t q = 0; q < nn; ++q) {
             const uint32_t i = idx[r.lo + q];
@@ -449,14 +534,14 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
             }
         });
     };
-    // hand a finished range to the caller: results, and the decoded bytes out of the pinned output slot
+    // hand a finished range to the caller: results, and (staged) the decoded bytes out of the pinned output slot
     auto unpack = [&](const Range &r, int s) {
         const size_t nn = r.hi - r.lo;
         uint64_t *ioff, *ilen, *ooff, *ocap, *olen, *used;
         int32_t *st;
         uint32_t *ad, *det;
         meta_ptrs(ln.h_meta[s].p, nn, ioff, ilen, ooff, ocap, olen, used, st, ad, det);
-        const uint8_t *src = ln.h_out[s].p;
+        const uint8_t *src = pinned ? nullptr : ln.h_out[s].p;
         ctx->helpers->run(helpers, [&](unsigned t, unsigned parts) {
             const size_t q0 = nn * t / parts, q1 = nn * (t + 1) / parts;
             for (size_t q = q0; q < q1; ++q) {
@@ -470,7 +555,7 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
                     b.detail[2 * (size_t)i + 1] = det[2 * q + 1];
                 }
                 const uint64_t nb = olen[q] < ocap[q] ? olen[q] : ocap[q];
-                if (nb) memcpy(b.out_base + b.out_off[i], src + ooff[q], nb);
+                if (src && nb) memcpy(b.out_base + b.out_off[i], src + ooff[q], nb);
             }
         });
     };
@@ -524,7 +609,6 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
     };
     std::thread drainer;
     if (R > 1) drainer = std::thread(drain);
-    bool first_kernel = true;
     for (size_t c = 0; c < R && herr == hipSuccess; ++c) {
         const Range &r = rg[c];
         const int s = (int)(c % nslot);
@@ -542,8 +626,12 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         pack(r, s);
         t_pack += since(tp);
         uint8_t *dm = (uint8_t *)ln.d_meta[s].p;
+        uint8_t *din = (uint8_t *)ln.d_in[pinned ? 0 : s].p, *dout = (uint8_t *)ln.d_out[pinned ? 0 : s].p;
         LANE_TRY(hipMemcpyAsync(dm, ln.h_meta[s].p, 32 * nn, hipMemcpyHostToDevice, s_up));  // the four extent arrays
-        if (r.in_bytes) LANE_TRY(hipMemcpyAsync(ln.d_in[s].p, ln.h_in[s].p, r.in_bytes, hipMemcpyHostToDevice, s_up));
+        if (r.in_bytes) {
+            if (pinned) LANE_TRY(hipMemcpyAsync(din + (r.in_lo - g_in_lo), b.in_base + r.in_lo, r.in_bytes, hipMemcpyHostToDevice, s_up));
+            else LANE_TRY(hipMemcpyAsync(din, ln.h_in[s].p, r.in_bytes, hipMemcpyHostToDevice, s_up));
+        }
         if (R > 1) {
             LANE_TRY(hipEventRecord(ln.ev_up[s], s_up));
             LANE_TRY(hipStreamWaitEvent(ln.s_k, ln.ev_up[s], 0));
@@ -553,8 +641,8 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         int32_t *st;
         uint32_t *ad, *det;
         meta_ptrs(dm, nn, ioff, ilen, ooff, ocap, olen, used, st, ad, det);
-        a.in_base = (const uint8_t *)ln.d_in[s].p;
-        a.out_base = (uint8_t *)ln.d_out[s].p;
+        a.in_base = din;
+        a.out_base = dout;
         a.in_off = ioff;
         a.in_len = ilen;
         a.out_off = ooff;
@@ -573,23 +661,23 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
 #if defined(PZG_PROFILE)
         a.prof_out = ctx->prof_buf ? (uint64_t *)ctx->prof_buf + 16 * (size_t)r.lo : nullptr;
 #endif
-        if (first_kernel) {
-            std::lock_guard<std::mutex> g(sh.mu);
-            LANE_TRY(hipEventRecord(sh.ev0, ln.s_k));
-            first_kernel = false;
+        if (c == 0) LANE_TRY(hipEventRecord(ln.ev_t0, ln.s_k));
+        if (pinned && r.mixed) {  // the caller's order stays: the longest streams are launched first through a permutation
+            uint32_t *ord = (uint32_t *)ln.d_ord[s].p;
+            LANE_TRY(pzg::launch_order(ocap, a.n, ord + 256, ord, ln.s_k));
+            a.order = ord + 256;
         }
         LANE_TRY(pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, ln.s_k));
-        if (c + 1 == R) {
-            std::lock_guard<std::mutex> g(sh.mu);
-            LANE_TRY(hipEventRecord(sh.ev1, ln.s_k));
-            sh.timed = true;
-        }
+        if (c + 1 == R) LANE_TRY(hipEventRecord(ln.ev_t1, ln.s_k));
         if (R > 1) {
             LANE_TRY(hipEventRecord(ln.ev_k[s], ln.s_k));
             LANE_TRY(hipStreamWaitEvent(s_dn, ln.ev_k[s], 0));
         }
         LANE_TRY(hipMemcpyAsync(ln.h_meta[s].p + 32 * nn, dm + 32 * nn, 32 * nn, hipMemcpyDeviceToHost, s_dn));  // results
-        if (r.out_bytes) LANE_TRY(hipMemcpyAsync(ln.h_out[s].p, ln.d_out[s].p, r.out_bytes, hipMemcpyDeviceToHost, s_dn));
+        if (r.out_bytes) {
+            if (pinned) LANE_TRY(hipMemcpyAsync(b.out_base + r.out_lo, dout + (r.out_lo - g_out_lo), r.out_bytes, hipMemcpyDeviceToHost, s_dn));
+            else LANE_TRY(hipMemcpyAsync(ln.h_out[s].p, dout, r.out_bytes, hipMemcpyDeviceToHost, s_dn));
+        }
         LANE_TRY(hipEventRecord(ln.ev_dn[s], s_dn));
         if (herr == hipSuccess) {
             {
@@ -622,11 +710,20 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         lane_drain(ln);
         return hip_fail(ctx, herr, hwhat);
     }
+    {   // the call's kernel span, measured by the call itself on its own lane's events (pzg_last_kernel_ms): calls of
+        // other threads on other lanes cannot get between the two
+        float ms = -1.0f;
+        const bool ok = hipEventSynchronize(ln.ev_t1) == hipSuccess && hipEventElapsedTime(&ms, ln.ev_t0, ln.ev_t1) == hipSuccess;
+        std::lock_guard<std::mutex> g(sh.mu);
+        sh.host_ms = ok ? (double)ms : -1.0;
+        sh.last_was_host = true;
+        sh.timed = true;
+    }
     if (trace)
-        fprintf(stderr, "[pzg] host path: %u streams, %.1f MiB in, %.1f MiB out (packed), %zu range(s), %u helper thread(s): %.1f ms "
-                "(packing %.1f on the issuing thread; on the draining thread: waiting for downloads %.1f, copy-out %.1f)\n", m, tot_in / 1048576.0,
-                tot_out / 1048576.0, R, helpers, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count(),
-                t_pack, t_wait, t_unpack);
+        fprintf(stderr, "[pzg] host path%s: %u streams, %.1f MiB in, %.1f MiB out, %zu range(s), %u helper thread(s): %.1f ms "
+                "(packing %.1f on the issuing thread; on the draining thread: waiting for downloads %.1f, copy-out %.1f)\n", pinned ? " (pinned arenas)" : "",
+                m, tot_in / 1048576.0, tot_out / 1048576.0, R, helpers,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call0).count(), t_pack, t_wait, t_unpack);
     return PZG_RC_OK;
 }
 
@@ -751,20 +848,54 @@ int pzg_init_mask(uint32_t device_mask, pzg_ctx **out)
         hipError_t e = hipGetDeviceCount(&ndev);
         if (e != hipSuccess || ndev <= 0) return PZG_RC_NO_DEVICE;
         if (device_mask == 0) device_mask = ndev >= 32 ? ~0u : (1u << ndev) - 1u;  // 0 = every visible device
-        // test knob: every shard of the mask on ONE physical device (a 1-GPU box exercises the multi-shard path)
-        const char *fold = getenv("PZG_FOLD_DEVICES");
         std::vector<int> devs;
         for (int d = 0; d < 32; ++d)
             if (device_mask & (1u << d)) {
-                if (!fold && d >= ndev) return PZG_RC_BAD_ARG;
-                devs.push_back(fold ? atoi(fold) : d);
+                if (d >= ndev) return PZG_RC_BAD_ARG;
+                devs.push_back(d);
             }
         if (devs.empty()) return PZG_RC_BAD_ARG;
-        if (fold && (atoi(fold) < 0 || atoi(fold) >= ndev)) return PZG_RC_BAD_ARG;
         return ctx_create(devs, out);
     } catch (...) {
         return PZG_RC_NO_MEMORY;
     }
+}
+
+int pzg_init_devices(const int32_t *devices, uint32_t ndevices, pzg_ctx **out)
+{
+    if (!out) return PZG_RC_BAD_ARG;
+    *out = nullptr;
+    if (!devices || ndevices == 0 || ndevices > 64u) return PZG_RC_BAD_ARG;
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) return PZG_RC_NO_DEVICE;
+        std::vector<int> devs;
+        for (uint32_t k = 0; k < ndevices; ++k) {
+            if (devices[k] < 0 || devices[k] >= ndev) return PZG_RC_BAD_ARG;
+            devs.push_back((int)devices[k]);  // (a device may be named more than once: one shard per entry)
+        }
+        return ctx_create(devs, out);
+    } catch (...) {
+        return PZG_RC_NO_MEMORY;
+    }
+}
+
+void *pzg_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 1;
+    // portable: page-locked for every device of the node (a multi-device context's copy engines all read / write it)
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void pzg_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int pzg_device_count(pzg_ctx *ctx) { return ctx_live(ctx) ? (int)ctx->shards.size() : 0; }
@@ -774,10 +905,12 @@ void pzg_shutdown(pzg_ctx *ctx)
     if (!ctx) return;
     if (ctx->closed.exchange(true)) return;  // (a second shutdown while decoders keep the context alive: nothing to drop)
     // quiet before the handle goes: nothing enqueued through it may still be running on caller memory
+    // (device-wide, not per stream: a stream borrowed through pzg_set_stream may already have been destroyed by its owner
+    // -- finalisers run in any order -- and its handle must not be touched; whatever was enqueued on it is waited for here)
     for (auto &s : ctx->shards) {
         std::lock_guard<std::mutex> g(s->mu);
-        if (hipSetDevice(s->device) == hipSuccess) (void)hipStreamSynchronize(s->stream);
-        s->stream = s->own_stream;  // a borrowed stream (pzg_set_stream) may not outlive this call on the caller's side
+        if (hipSetDevice(s->device) == hipSuccess) (void)hipDeviceSynchronize();
+        s->stream = s->own_stream;
     }
     ctx_unref(ctx);  // live decoders hold their own references: the last pzg_decoder_destroy frees the context
 }
@@ -805,6 +938,14 @@ int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
     if (!ctx_live(ctx)) return PZG_RC_BAD_ARG;
     if (option == PZG_OPT_RING_BITS && value >= 11 && value <= 15) {
         ctx->ring_bits = (int)value;
+        return PZG_RC_OK;
+    }
+    if (option == PZG_OPT_HOST_THREADS && value >= 1 && value <= 256) {  // (not while host-pointer calls are running)
+        try {
+            ctx->helpers.reset(new Helpers((unsigned)value));
+        } catch (...) {
+            return PZG_RC_NO_MEMORY;
+        }
         return PZG_RC_OK;
     }
     return PZG_RC_BAD_ARG;
@@ -872,6 +1013,11 @@ int pzg_decompress_many_dict(pzg_ctx *ctx, const uint8_t *in_base, const uint64_
             any_out |= out_cap[i] != 0;
         }
         if (any_out && !out_base) return PZG_RC_BAD_ARG;
+        if (flags & PZG_HOST_PINNED) {  // the copy engines move whole spans of the arenas: extents ascend, none overlaps the next
+            if (with_dict) return PZG_RC_BAD_ARG;
+            for (uint32_t i = 0; i + 1 < n; ++i)
+                if (in_off[i] + in_len[i] > in_off[i + 1] || out_off[i] + out_cap[i] > out_off[i + 1]) return PZG_RC_BAD_ARG;
+        }
         HostBatch b{in_base, in_off, in_len, out_base, out_off, out_cap, out_len, status, detail, in_used, adler, flags};
         if (with_dict) {
             bool any = false;
@@ -885,21 +1031,32 @@ int pzg_decompress_many_dict(pzg_ctx *ctx, const uint8_t *in_base, const uint64_
         if (S == 1) {
             std::vector<uint32_t> idx(n);
             std::iota(idx.begin(), idx.end(), 0u);
-            lpt_order(out_cap, idx);
+            if (!(flags & PZG_HOST_PINNED)) lpt_order(out_cap, idx);
             return host_path(ctx, *ctx->shards[0], b, idx.data(), n);
         }
         // several devices: longest-processing-time-first over the shards (by capacity), one host thread per shard
         std::vector<uint32_t> all(n);
         std::iota(all.begin(), all.end(), 0u);
-        lpt_order(out_cap, all);
         std::vector<std::vector<uint32_t>> part(S);
-        std::vector<uint64_t> load(S, 0);
-        for (uint32_t i : all) {
-            size_t best = 0;
-            for (size_t s = 1; s < S; ++s)
-                if (load[s] < load[best]) best = s;
-            part[best].push_back(i);
-            load[best] += out_cap[i] + in_len[i] + 4096;  // (+ a per-stream constant: tiny streams are not free)
+        if (flags & PZG_HOST_PINNED) {  // contiguous index slices of (nearly) equal load: every shard moves its own span of the arenas
+            uint64_t total = 0, acc = 0;
+            for (uint32_t i = 0; i < n; ++i) total += out_cap[i] + in_len[i] + 4096;
+            size_t s = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                while (s + 1 < S && acc >= total * (s + 1) / S) ++s;
+                part[s].push_back(i);
+                acc += out_cap[i] + in_len[i] + 4096;
+            }
+        } else {
+            lpt_order(out_cap, all);
+            std::vector<uint64_t> load(S, 0);
+            for (uint32_t i : all) {
+                size_t best = 0;
+                for (size_t s = 1; s < S; ++s)
+                    if (load[s] < load[best]) best = s;
+                part[best].push_back(i);
+                load[best] += out_cap[i] + in_len[i] + 4096;  // (+ a per-stream constant: tiny streams are not free)
+            }
         }
         std::vector<int> rcs(S, PZG_RC_OK);
         auto run_shard = [&](size_t s) noexcept {
@@ -1043,8 +1200,7 @@ void pzg_decoder_destroy(pzg_decoder *dec)
     if (dec->stream) (void)hipStreamSynchronize(dec->stream);
     for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta})
         if (a->p) (void)hipFree(a->p);
-    for (Pinned *h : {&dec->h_in, &dec->h_out, &dec->h_meta})
-        if (h->p) (void)hipHostFree(h->p);
+    for (Pinned *h : {&dec->h_in, &dec->h_out, &dec->h_meta}) pinned_release(*h);
     if (dec->d_state) (void)hipFree(dec->d_state);
     if (dec->d_counter) (void)hipFree(dec->d_counter);
     if (dec->stream) (void)hipStreamDestroy(dec->stream);
@@ -1257,6 +1413,7 @@ int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init, u
             HIP_TRY(ctx, pzg::launch_adler32(buf, len, init, partials, ADLER_MAX_WAVES, out, s));
             HIP_TRY(ctx, hipEventRecord(sh.ev1, s));
             sh.timed = true;
+            sh.last_was_host = false;
             if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(s));
             return PZG_RC_OK;
         }
@@ -1268,6 +1425,7 @@ int pzg_adler32(pzg_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t init, u
         HIP_TRY(ctx, pzg::launch_adler32(d_buf, len, init, partials, ADLER_MAX_WAVES, d_res, s));
         HIP_TRY(ctx, hipEventRecord(sh.ev1, s));
         sh.timed = true;
+        sh.last_was_host = false;
         HIP_TRY(ctx, hipMemcpyAsync(out, d_res, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
         return PZG_RC_OK;
@@ -1289,6 +1447,7 @@ int pzg_adler32_many(pzg_ctx *ctx, const uint8_t *base, const uint64_t *off, con
     HIP_TRY(ctx, pzg::launch_adler32_many(base, off, len, out, n, sh.num_cus, sh.stream));
     HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
     sh.timed = true;
+    sh.last_was_host = false;
     if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(sh.stream));
     return PZG_RC_OK;
 }
@@ -1299,6 +1458,7 @@ double pzg_last_kernel_ms(pzg_ctx *ctx)
     Shard &sh = *ctx->shards[0];
     std::lock_guard<std::mutex> g(sh.mu);
     if (!sh.timed) return -1.0;
+    if (sh.last_was_host) return sh.host_ms;
     if (hipSetDevice(sh.device) != hipSuccess) return -1.0;
     if (hipEventSynchronize(sh.ev1) != hipSuccess) return -1.0;
     float ms = -1.0f;

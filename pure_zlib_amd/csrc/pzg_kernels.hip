@@ -310,7 +310,9 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
                             : ring_bits == 13 ? waves_per_cu<13>() : ring_bits == 12 ? waves_per_cu<12>()
                             : a.gzip ? waves_per_cu<11, true>() : waves_per_cu<11>();
     uint32_t waves = (uint32_t)num_cus * per_cu;
-    if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);  // experiment knob
+#if defined(PZG_LAB)   // lab builds only (tests/tools/exp_build.sh -DPZG_LAB): the residency sweep
+    if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);
+#endif
     if (waves > a.n) waves = a.n;
     dim3 grid(waves), block(64);
     // Ring size classes.  15: the whole 32 KiB DEFLATE window is an LDS ring (4 stream-waves per CU).

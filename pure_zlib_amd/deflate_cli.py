@@ -4,8 +4,9 @@ SURVEY.md section 8f row 2 ("next" row).  Same messages as the reference; the fi
 size `L.readFile` uses (bytestring's defaultChunkSize = 32 KiB minus two words) and driven through
 the ZlibDecoder protocol exactly like `runDecompression` (Deflate.hs:30-48).
 
-Batch mode (on top of the reference):  deflate a.z b.z c.z ...  decodes every file in ONE
-`decompressMany` call -- one wavefront per file, one launch -- and writes a, b, c.  Each file is handed over as the lazy
+Batch mode (on top of the reference; behind its own flag so that everything the reference's
+binary prints -- "USAGE: deflate [filename]" for anything but exactly one argument -- stays as it is):
+deflate --many a.z b.z c.z ...  decodes every file in ONE `decompressMany` call -- one wavefront per file, one launch -- and writes a, b, c.  Each file is handed over as the lazy
 ByteString `L.readFile` would make of it, so `decompress`'s own outcomes apply per file: "ERROR: <show e>" for a Left
 (including Zlib.hs:48-49's "Finished with data remaining."), "Unexpected file name." for a name that does not end in
 ".z"; the other files are still decoded.
@@ -64,10 +65,10 @@ def run_many(files) -> None:
 
 def main(argv=None) -> int:
     args = sys.argv[1:] if argv is None else argv
-    if len(args) > 1:
-        run_many(args)
+    if args and args[0] == "--many":
+        run_many(args[1:])
         return 0
-    if len(args) != 1:
+    if len(args) != 1:  # Deflate.hs:17-29
         print("USAGE: deflate [filename]")
         return 0
     ifile = args[0]

@@ -138,12 +138,16 @@ def error_from_status(stream: bytes, status: int, detail) -> DecompressionError:
 class Context:
     """One pzg_ctx (HIP device + stream + staging arenas)."""
 
-    def __init__(self, device: int = 0, device_mask: Optional[int] = None):
+    def __init__(self, device: int = 0, device_mask: Optional[int] = None, devices: Optional[Sequence[int]] = None):
         """device: one HIP device.  device_mask: several devices of one node (bit d = device d, 0 = all visible):
-        decompress_many then shards a host batch over them inside the library (pzg_init_mask)."""
+        decompress_many then shards a host batch over them inside the library (pzg_init_mask).  devices: the same with
+        the devices named one by one, one shard per entry (pzg_init_devices; a device may appear more than once)."""
         L = _ffi.lib()
         h = C.c_void_p()
-        if device_mask is None:
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            _ffi.check(L.pzg_init_devices(arr, len(devices), C.byref(h)))
+        elif device_mask is None:
             _ffi.check(L.pzg_init(device, C.byref(h)))
         else:
             _ffi.check(L.pzg_init_mask(device_mask, C.byref(h)))
@@ -189,6 +193,10 @@ class Context:
         """LDS near-ring size class (11..15; 15 = the whole 32 KiB window in LDS).  Results are identical."""
         _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_RING_BITS, int(ring_bits)), self._h)
 
+    def set_host_threads(self, n: int):
+        """Helper threads of the staged host-pointer path and of the decoders' feeds (PZG_OPT_HOST_THREADS)."""
+        _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_HOST_THREADS, int(n)), self._h)
+
     def sync(self):
         _ffi.check(self._L.pzg_sync(self._h), self._h)
 
@@ -197,8 +205,9 @@ class Context:
 
     # -- raw batched call on host memory ----------------------------------------------------------
     def decompress_many_raw(self, in_buf: np.ndarray, in_off, in_len, out_buf: np.ndarray, out_off, out_cap, gzip: bool = False,
-                            dict_buf: Optional[np.ndarray] = None, dict_off=None, dict_len=None):
+                            dict_buf: Optional[np.ndarray] = None, dict_off=None, dict_len=None, pinned: bool = False):
         """Thin wrapper of pzg_decompress_many on host numpy buffers.
+        pinned: in_buf / out_buf are page-locked arenas (pinned_array) with ascending extents -- PZG_HOST_PINNED.
         Returns (out_len u64[n], status i32[n], detail u32[n,2], in_used u64[n], adler u32[n])."""
         in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
         in_len = np.ascontiguousarray(in_len, dtype=np.uint64)
@@ -226,7 +235,7 @@ class Context:
         rc = self._L.pzg_decompress_many(
             self._h, in_buf.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, out_buf.ctypes.data,
             out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data, status.ctypes.data, detail.ctypes.data,
-            in_used.ctypes.data, adler.ctypes.data, n, _ffi.GZIP if gzip else 0)
+            in_used.ctypes.data, adler.ctypes.data, n, (_ffi.GZIP if gzip else 0) | (_ffi.HOST_PINNED if pinned else 0))
         _ffi.check(rc, self._h)
         return out_len, status, detail, in_used, adler
 
@@ -265,6 +274,50 @@ class Context:
     def adler32_device(self, ptr: int, nbytes: int, out_ptr: int, init: int = 1, sync: bool = True):
         flags = _ffi.DEVICE_PTRS | (0 if sync else _ffi.ASYNC)
         _ffi.check(self._L.pzg_adler32(self._h, ptr, nbytes, init, out_ptr, flags), self._h)
+
+
+class PinnedArena:
+    """A page-locked host buffer from pzg_host_alloc, seen as a numpy uint8 array (`.a`).  The copy engines read and write
+    it directly (PZG_HOST_PINNED): what the mirrors pack their batches into, so that nothing is staged a second time."""
+
+    def __init__(self, nbytes: int):
+        self._L = _ffi.lib()
+        self.nbytes = max(int(nbytes), 1)
+        self._p = self._L.pzg_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError(f"pzg_host_alloc({self.nbytes}) failed: the system will not lock that much memory")
+        self.a = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self._p))
+
+    def close(self):
+        if self._p:
+            self.a = None
+            self._L.pzg_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# the mirrors' arenas: grow-only, one pair per thread (a `decompress` call is synchronous)
+_arenas = threading.local()
+
+
+def _arena(kind: str, nbytes: int) -> Optional[np.ndarray]:
+    """A page-locked array of at least nbytes for this thread's `kind` ("in" / "out"), or None when the system refuses."""
+    cur = getattr(_arenas, kind, None)
+    if cur is None or cur.nbytes < nbytes:
+        if cur is not None:
+            cur.close()
+        try:
+            cur = PinnedArena(max(nbytes, 1 << 20) * 5 // 4)
+        except MemoryError:
+            setattr(_arenas, kind, None)
+            return None
+        setattr(_arenas, kind, cur)
+    return cur.a
 
 
 _default_ctx = None
@@ -326,10 +379,17 @@ def decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = 
             in_off[k], out_off[k] = ipos, opos
             ipos += _align(int(in_len[k]), 16)
             opos += _align(int(out_cap[k]), 16)
-        in_buf = np.zeros(ipos + 16, dtype=np.uint8)
+        # packed into page-locked arenas (PZG_HOST_PINNED: the library then stages nothing a second time); preset dictionaries
+        # and a system that will not lock the memory take the staged path over ordinary arrays
+        in_buf = out_buf = None
+        if zdict is None:
+            in_buf, out_buf = _arena("in", ipos + 16), _arena("out", opos + 16)
+        pinned = in_buf is not None and out_buf is not None
+        if not pinned:
+            in_buf = np.zeros(ipos + 16, dtype=np.uint8)
+            out_buf = np.zeros(opos + 16, dtype=np.uint8)
         for k, i in enumerate(todo):
             in_buf[int(in_off[k]):int(in_off[k]) + len(flat[i])] = np.frombuffer(flat[i], dtype=np.uint8)
-        out_buf = np.zeros(opos + 16, dtype=np.uint8)
         dict_args = {}
         if zdict is not None:
             dl = np.array([len(zdict[i] or b"") for i in todo], dtype=np.uint64)
@@ -338,7 +398,7 @@ def decompress_many(streams: Sequence[LazyByteString], ctx: Optional[Context] = 
             db = np.frombuffer(b"".join((zdict[i] or b"") for i in todo) + b"\0" * 16, dtype=np.uint8)
             dict_args = dict(dict_buf=db, dict_off=do, dict_len=dl)
         out_len, status, detail, in_used, _adler = ctx.decompress_many_raw(in_buf, in_off, in_len, out_buf, out_off, out_cap, gzip,
-                                                                           **dict_args)
+                                                                           pinned=pinned, **dict_args)
         retry = []
         for k, i in enumerate(todo):
             st = int(status[k])

@@ -78,6 +78,7 @@ int pzm_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t ca
 int pzm_decompress_gzip(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, int ring_bits, pzm_result *r)
 {
     if (ring_bits == 15) run_one<15, true>(in, in_len, out, cap, r);
+    else if (ring_bits == 14) run_one<14, true>(in, in_len, out, cap, r);
     else if (ring_bits == 13) run_one<13, true>(in, in_len, out, cap, r);
     else if (ring_bits == 12) run_one<12, true>(in, in_len, out, cap, r);
     else if (ring_bits == 11) run_one<11, true>(in, in_len, out, cap, r);

@@ -74,8 +74,27 @@ def test_ring11_kernels_use_no_scratch():
 
 def test_version_and_strerror():
     L = _ffi.lib()
-    assert L.pzg_version() == 3  # (major << 16) | minor: 0.3 (round 3: reference-counted contexts, pzg_decompress_many_sharded)
+    assert L.pzg_version() == 4  # (major << 16) | minor: 0.4 (round 4: PZG_HOST_PINNED + pzg_host_alloc, pzg_init_devices, PZG_OPT_HOST_THREADS)
     assert b"no CPU fallback" in L.pzg_strerror(_ffi.RC_NO_DEVICE)
+
+
+def test_library_reads_no_undocumented_environment_knob():
+    """the product reads ONE environment variable, the documented PZG_RING_BITS (include/pzg.h); the
+    experiment knobs of earlier rounds live behind -DPZG_LAB, which csrc/Makefile never sets."""
+    import re
+    import subprocess
+    text = subprocess.check_output(["strings", "-a", _ffi.LIB_PATH]).decode(errors="replace")
+    assert set(re.findall(r"PZG_[A-Z_0-9]+", text)) == {"PZG_RING_BITS"}
+    with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", "Makefile")) as f:
+        assert "PZG_LAB" not in f.read()
+    for fn in ("inflate_core.h", "pzg_kernels.hip", "pzg_api.cpp"):
+        with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", fn)) as f:
+            src = f.read()
+        assert "PZG_EXP_" not in src and "PZG_NO_SUB" not in src and "PZG_FAR_NT" not in src, fn
+        for m in re.finditer(r'getenv\("(PZG_[A-Z_]+)"\)', src):
+            if m.group(1) != "PZG_RING_BITS":  # the rest only inside #if defined(PZG_LAB)
+                before = src[:m.start()]
+                assert before.rfind("#if defined(PZG_LAB)") > before.rfind("#endif"), (fn, m.group(1))
 
 
 def test_no_gpu_means_loud_failure():
@@ -154,11 +173,12 @@ def test_cxx_module_mirror_builds_and_fails_loudly_without_a_gpu(tmp_path):
 
 def noflags_library():
     """build/noflags/libpzg.so: the same sources WITHOUT csrc/Makefile's two -mllvm options (tests/tools/noflags_build.sh);
-    rebuilt when a kernel source is newer.  Test infrastructure (a compiler upgrade may change what the options mean: the
+    rebuilt when a source (kernels, API, header) is newer.  Test infrastructure (a compiler upgrade may change what the options mean: the
     library must be just as correct without them, only slower)."""
     import subprocess
     so = os.path.join(ROOT, "build", "noflags", "libpzg.so")
-    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_kernels.hip", "pzg_launch.h")]
+    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_kernels.hip", "pzg_launch.h", "pzg_api.cpp",
+                                                                    "pzg_errors.cpp", "pzg.map")] + [os.path.join(ROOT, "include", "pzg.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call([os.path.join(ROOT, "tests", "tools", "noflags_build.sh")])
     return so

@@ -16,19 +16,33 @@ from test_gpu_parity import run_batch
 pytestmark = pytest.mark.gpu
 
 
+def _shard_devices(k):
+    """The devices of a k-shard test context: the box's real devices when it has several (shard j on device j mod count --
+    a hipSetDevice / peer / pinned-memory mistake then shows), all k shards on device 0 on a one-GPU box."""
+    import torch
+    nd = torch.cuda.device_count()
+    return [j % nd for j in range(k)]
+
+
 def _mixed_batch(n):
     datas = [corpus.zipf_text(200 + (k * 7919) % 60000, k) if k % 3 else corpus.mixed_data((k * 131) % 9000, k) for k in range(n)]
     return [zlib.compress(d, 1 + k % 9) for k, d in enumerate(datas)], datas
 
 
 def test_decompress_many_sharded_over_a_device_mask(gpu_ctx, oracle, monkeypatch):
-    """pzg_init_mask: ONE pzg_decompress_many call partitions the streams over the mask's devices (here four shards
-    folded onto device 0 by the test knob, so the multi-shard path -- one host thread, stream set and arenas per shard,
-    results written straight into the caller's slots -- runs on a 1-GPU box).  Byte-identical to the single-device
-    result and to the oracle."""
+    """pzg_init_mask / pzg_init_devices: ONE pzg_decompress_many call partitions the streams over the context's shards
+    (four here: the box's own devices when it has several, all four on device 0 otherwise, so the multi-shard path -- one
+    host thread, stream set and arenas per shard, results written straight into the caller's slots -- runs on a 1-GPU
+    box and upgrades itself on a node).  Byte-identical to the single-device result and to the oracle."""
     import pure_zlib_amd as P
-    monkeypatch.setenv("PZG_FOLD_DEVICES", "0")
-    group = P.Context(device_mask=0b1111)
+    import torch
+    group = P.Context(devices=_shard_devices(4))
+    if torch.cuda.device_count() >= 2:  # the mask form over every visible device too
+        allm = P.Context(device_mask=0)
+        assert allm.device_count == torch.cuda.device_count()
+        streams0, datas0 = _mixed_batch(200)
+        assert P.decompress_many(streams0, ctx=allm) == [P.Right(d) for d in datas0]
+        allm.close()
     try:
         assert group.device_count == 4 and gpu_ctx.device_count == 1
         streams, datas = _mixed_batch(3000)
@@ -260,19 +274,21 @@ print("noflags parity ok", len(streams))
 def test_decompress_many_sharded_device_pointers(gpu_ctx, oracle, monkeypatch):
     """pzg_decompress_many_sharded: data ALREADY on the devices -- one batch of device pointers per
     shard, every batch enqueued on its own device's stream by one call, nothing staged through the host.  Three shards
-    folded onto device 0 (the test knob), four batches (two on one shard), synchronous and PZG_ASYNC + pzg_sync; every
-    stream against the plaintext, samples against the oracle; bad arguments refused."""
+    (the box's own devices when it has several -- every batch then lives on ITS shard's device -- else all on device 0),
+    four batches (two on one shard), synchronous and PZG_ASYNC + pzg_sync; every stream against the plaintext, samples
+    against the oracle; bad arguments refused."""
     import pure_zlib_amd as P
+    import torch
     from devbatch import DeviceBatch
     from pure_zlib_amd._ffi import PzgError
-    monkeypatch.setenv("PZG_FOLD_DEVICES", "0")
-    group = P.Context(device_mask=0b111)
+    devs = _shard_devices(3)
+    group = P.Context(devices=devs)
     try:
         texts = [corpus.zipf_text(1024 * (1 + (k * 37) % 48), k) for k in range(256)]
         zs = [zlib.compress(t, 6) for t in texts]
         rng = np.random.default_rng(3)
-        parts = [DeviceBatch(texts, zs, rng.integers(0, len(zs), size=n)) for n in (5000, 3000, 7000, 11)]
         shard_of = [0, 1, 2, 1]
+        parts = [DeviceBatch(texts, zs, rng.integers(0, len(zs), size=n), dev=devs[sh]) for n, sh in zip((5000, 3000, 7000, 11), shard_of)]
 
         def as_batches():
             return [dict(shard=s, n=b.n, in_base=b.d_in.data_ptr(), in_off=b.d_in_off.data_ptr(), in_len=b.d_in_len.data_ptr(),
@@ -286,7 +302,8 @@ def test_decompress_many_sharded_device_pointers(gpu_ctx, oracle, monkeypatch):
             for b in parts:
                 b.d_out.fill_(0xCD)
                 b.d_status.fill_(-1)
-            b.torch.cuda.synchronize()
+            for d in set(devs):
+                torch.cuda.synchronize(d)
             group.decompress_many_sharded(as_batches(), sync=sync, lpt=not sync)
             if not sync:
                 group.sync()
@@ -337,3 +354,99 @@ def test_host_path_pipelined_ranges_back_to_back_extents(gpu_ctx):
     body = out_buf[guard:guard + n * 16384].reshape(n, 16384)
     pool = np.frombuffer(b"".join(texts), dtype=np.uint8).reshape(len(texts), 16384)
     assert np.array_equal(body[good], pool[pick][good])
+
+
+def test_host_pinned_arenas(gpu_ctx, oracle):
+    """PZG_HOST_PINNED: arenas from pzg_host_alloc are read and written by the copy engines directly --
+    the path the module mirrors take.  The same batch staged and pinned: identical results; mixed sizes (launched longest
+    first through the device-side permutation), a batch big enough for several pipelined ranges, bad streams among them,
+    the bytes in front of and behind the spans untouched; extents out of order are refused; a multi-shard context moves
+    one span per shard."""
+    import pure_zlib_amd as P
+    from pure_zlib_amd._ffi import PzgError
+    from pure_zlib_amd.zlib import PinnedArena
+    texts = [corpus.zipf_text(1024 * (1 + (k * 37) % 48), k) for k in range(256)]
+    zs = [zlib.compress(t, 6) for t in texts]
+    rng = np.random.default_rng(5)
+    for n in (300, 9000):  # one range / several ranges (> 96 MiB)
+        pick = rng.integers(0, len(zs), size=n)
+        streams = [zs[k] for k in pick]
+        streams[7] = streams[7][:-9]                       # truncated
+        streams[n - 5] = zlib.compress(texts[3] * 3, 6)    # outgrows its capacity
+        in_len = np.array([len(s) for s in streams], dtype=np.uint64)
+        out_cap = np.array([len(texts[k]) for k in pick], dtype=np.uint64)
+        guard = 4096 + 16
+        in_off = guard + np.concatenate([[0], np.cumsum((in_len[:-1] + 15) // 16 * 16)]).astype(np.uint64)
+        out_off = guard + np.concatenate([[0], np.cumsum((out_cap[:-1] + 15) // 16 * 16)]).astype(np.uint64)
+        a_in = PinnedArena(int(in_off[-1] + in_len[-1]) + guard)
+        a_out = PinnedArena(int(out_off[-1] + out_cap[-1]) + guard)
+        a_in.a[:] = 0xEE
+        for k, s in enumerate(streams):
+            a_in.a[int(in_off[k]):int(in_off[k]) + len(s)] = np.frombuffer(s, dtype=np.uint8)
+        ref_out = np.full(a_out.nbytes, 0xCD, dtype=np.uint8)
+        ref = gpu_ctx.decompress_many_raw(a_in.a.copy(), in_off, in_len, ref_out, out_off, out_cap)  # staged, pageable
+        for ctx in (gpu_ctx, None):
+            group = None
+            if ctx is None:
+                group = ctx = P.Context(devices=_shard_devices(3))
+            try:
+                a_out.a[:] = 0xCD
+                got = ctx.decompress_many_raw(a_in.a, in_off, in_len, a_out.a, out_off, out_cap, pinned=True)
+                for x, y in zip(ref, got):
+                    assert np.array_equal(x, y)
+                assert got[1][7] == 1 and got[1][n - 5] == 14 and int((got[1] == 0).sum()) == n - 2
+                for k in range(n):
+                    nb = int(min(got[0][k], out_cap[k]))
+                    lo = int(out_off[k])
+                    assert np.array_equal(a_out.a[lo:lo + nb], ref_out[lo:lo + nb]), k
+                assert (a_out.a[:guard] == 0xCD).all() and (a_out.a[int(out_off[-1] + out_cap[-1]):] == 0xCD).all()
+            finally:
+                if group is not None:
+                    group.close()
+        r, o = oracle.decompress(streams[11], int(out_cap[11]))
+        assert r.status == 0 and a_out.a[int(out_off[11]):int(out_off[11]) + int(out_cap[11])].tobytes() == o
+        # extents must ascend
+        swapped = out_off.copy()
+        swapped[[3, 4]] = swapped[[4, 3]]
+        with pytest.raises(PzgError):
+            gpu_ctx.decompress_many_raw(a_in.a, in_off, in_len, a_out.a, swapped, out_cap, pinned=True)
+        a_in.close()
+        a_out.close()
+    # the mirrors pack into page-locked arenas themselves
+    assert P.decompress_many(zs[:40], ctx=gpu_ctx) == [P.Right(t) for t in texts[:40]]
+
+
+def test_overlapping_async_launches_on_two_streams(gpu_ctx):
+    """two PZG_ASYNC | PZG_LPT_ORDER launches (one of them gzip) enqueued on two different user streams
+    may run at the same time: each has its own work counter, launch permutation and expected-CRC array."""
+    import struct
+    import torch
+    from devbatch import DeviceBatch
+    texts = [corpus.zipf_text(1024 * (1 + (s * 2654435761 >> 7) % 64), s) for s in range(128)]
+    zs = [zlib.compress(t, 6) for t in texts]
+    gz = [b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + z[2:-4] + struct.pack("<II", zlib.crc32(t), len(t)) for z, t in zip(zs, texts)]
+    rng = np.random.default_rng(21)
+    a = DeviceBatch(texts, zs, rng.integers(0, len(zs), size=30000))
+    b = DeviceBatch(texts, gz, rng.integers(0, len(zs), size=20000))
+    c = DeviceBatch(texts, zs, rng.integers(0, len(zs), size=25000))
+    s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    try:
+        for rounds in range(3):
+            for x in (a, b, c):
+                x.d_out.fill_(0xCD)
+                x.d_status.fill_(-1)
+            torch.cuda.synchronize()
+            for x, st, g in ((a, s1, False), (b, s2, True), (c, s3, False)):
+                gpu_ctx.set_stream(st.cuda_stream)
+                gpu_ctx.decompress_many_device(x.d_in.data_ptr(), x.d_in_off.data_ptr(), x.d_in_len.data_ptr(), x.d_out.data_ptr(),
+                                               x.d_out_off.data_ptr(), x.d_out_cap.data_ptr(), x.d_out_len.data_ptr(), x.d_status.data_ptr(),
+                                               x.d_detail.data_ptr(), x.d_in_used.data_ptr(), x.d_adler.data_ptr(), x.n, sync=False, gzip=g, lpt=True)
+            torch.cuda.synchronize()
+            a.check_all(a.d_status.cpu().numpy(), a.d_out_len.cpu().numpy(), a.d_in_used.cpu().numpy(), a.d_adler.cpu().numpy().view(np.uint32))
+            c.check_all(c.d_status.cpu().numpy(), c.d_out_len.cpu().numpy(), c.d_in_used.cpu().numpy(), c.d_adler.cpu().numpy().view(np.uint32))
+            assert (b.d_status.cpu().numpy() == 0).all() and (b.d_out_len.cpu().numpy() == b.out_cap).all()
+            crc = np.array([zlib.crc32(t) for t in texts], dtype=np.uint32)[b.pick]
+            assert (b.d_adler.cpu().numpy().view(np.uint32) == crc).all()
+    finally:
+        gpu_ctx.reset_stream()

@@ -2,7 +2,11 @@
 resident in HBM exactly as bench.py's timed region hands them over:
 
   config 3   65,536 x 4 KiB fixed-Huffman (Z_FIXED, level 1) blobs  -- rings 11 and 15
+  config 4   65,536 x 32 KiB dynamic-Huffman (level 6) blobs         -- rings 11 and 15
   config 5   131,072 mixed 1-64 KiB level-6 blobs = its per-GPU share (1 M streams over 8 GPUs)
+  config 2   Adler-32 over one 16 GiB buffer
+  > 4 GiB    one stream that decodes to more than 4 GiB and one whose COMPRESSED form is more than 4 GiB (include/pzg.h:
+             "one compressed stream up to 16 GiB ... the decoded size is not limited")
   N > 1      bench.py ITSELF under torch.distributed.run with two ranks (both on device 0, gloo rendezvous:
              RCCL refuses two ranks on one GPU): the sharding, the barrier, MAX of the time, MIN of bit_exact
 
@@ -41,6 +45,21 @@ def test_config3_65536_fixed_huffman_4k_blobs(gpu_ctx, oracle):
     texts, zs = _fixed_pool(1024)
     assert all((z[2] >> 1) & 3 == 1 for z in zs)  # BTYPE 01: fixed Huffman
     pick = np.random.default_rng(0xC3).integers(0, len(zs), size=65536)
+    b = DeviceBatch(texts, zs, pick)
+    for ring in (11, 15):
+        res = b.run(gpu_ctx, ring)
+        b.check_all(*res)
+        b.check_sample_vs_oracle(oracle, 256)
+    gpu_ctx.set_ring_bits(11)
+
+
+def test_config4_65536_level6_32k_blobs(gpu_ctx, oracle):
+    """BASELINE config 4 at full size (the batch bench.py times), under -m gpu: 65,536 x 32 KiB level-6 blobs, every
+    stream's status / length / in_used / Adler-32, every decoded byte, 256 sampled streams against the oracle -- on the
+    default hybrid ring and on north_star's literal 32 KiB LDS ring."""
+    texts = [corpus.zipf_text(32768, seed) for seed in range(2048)]
+    zs = [zlib.compress(t, 6) for t in texts]
+    pick = np.random.default_rng(0xC4).integers(0, len(zs), size=65536)
     b = DeviceBatch(texts, zs, pick)
     for ring in (11, 15):
         res = b.run(gpu_ctx, ring)
@@ -124,17 +143,17 @@ def test_bench_py_config5_command_two_ranks():
     assert "config 5" in r["config"]["workload"] and r["value"] > 0
 
 
-def test_adler32_over_one_9_gib_device_buffer(gpu_ctx):
-    """BASELINE config 2 beyond 4 GiB under -m gpu: one 9 GiB device buffer, SURVEY.md 8d's splitmix64 bytes,
+def test_adler32_over_one_16_gib_device_buffer(gpu_ctx):
+    """BASELINE config 2 at its full 16 GiB under -m gpu: one 16 GiB device buffer, SURVEY.md 8d's splitmix64 bytes,
     against chunked zlib.adler32 over the CPU generator's bytes (Adler32.hs:37-57: the combine step multiplies a block's
     byte sum by the length that follows it, a 64-bit number here, modulo 65521).  Also an unaligned start and an odd length."""
     import torch
     dev = torch.device("cuda", 0)
-    nwords = (9 << 30) // 8
+    nwords = (16 << 30) // 8
     buf = torch.empty(nwords, dtype=torch.int64, device=dev)
     chunk = 1 << 25  # words: 256 MiB
     exp, exp_odd = 1, 1
-    skew, tail_cut = 5, 3  # the second checksum runs over bytes [5, 9 GiB - 3)
+    skew, tail_cut = 5, 3  # the second checksum runs over bytes [5, 16 GiB - 3)
     for lo in range(0, nwords, chunk):
         cnt = min(chunk, nwords - lo)
         buf[lo:lo + cnt] = corpus.splitmix64_torch(lo, cnt, dev)
@@ -152,3 +171,86 @@ def test_adler32_over_one_9_gib_device_buffer(gpu_ctx):
     got = res.cpu().numpy().view(np.uint32)
     assert int(got[0]) == exp and int(got[1]) == exp_odd, (hex(int(got[0])), hex(exp), hex(int(got[1])), hex(exp_odd))
     del buf
+
+
+def test_streams_beyond_4_gib(gpu_ctx):
+    """include/pzg.h: "one compressed stream up to 16 GiB (the reader indexes dwords with 32 bits); the decoded size is not
+    limited".  Two streams in one launch, each on one wavefront, rings 11 and 15:
+      A  decodes to 4,200 MiB (> 2^32 bytes): 4,200 copies of one full-flushed raw-deflate segment (1 MiB of byte runs and short
+         repeating patterns: dist < len copies, far reads, thousands of blocks) between a zlib header and a final empty block;
+      B  is 4.3 GB COMPRESSED: 65,600 stored blocks of 65,535 random bytes (level 0), so the bit reader restarts beyond byte 2^32.
+    Checked: status, out_len, in_used, the Adler-32 against zlib.adler32 streamed over the plaintext, and EVERY decoded byte on
+    the device against the plaintext.  (The bit-at-a-time oracle would need minutes per stream here: the plaintext the streams
+    were made from and system zlib's checksum are the references, as for every valid stream.)"""
+    import struct
+    import torch
+    dev = torch.device("cuda", 0)
+    # ---- A
+    unit = b"".join(corpus.mixed_data(65536, 2 + (k & 1) + 4 * k) for k in range(16))
+    assert len(unit) == 1 << 20
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    seg = co.compress(unit) + co.flush(zlib.Z_FULL_FLUSH)  # whole blocks, byte aligned, no reference across the flush
+    reps_a = 4200
+    ad_a = 1
+    for _ in range(reps_a):
+        ad_a = zlib.adler32(unit, ad_a)
+    za = b"\x78\x9c" + seg * reps_a + b"\x03\x00" + struct.pack(">I", ad_a)
+    assert zlib.decompress(b"\x78\x9c" + seg * 2 + b"\x03\x00" + struct.pack(">I", zlib.adler32(unit * 2))) == unit * 2
+    len_a = reps_a << 20
+    assert len_a > 1 << 32
+    # ---- B
+    nblk = 65600
+    rng = np.random.default_rng(0xB16)
+    zb = np.empty(2 + nblk * 65540 + 4, dtype=np.uint8)
+    zb[0], zb[1] = 0x78, 0x01
+    blocks = zb[2:2 + nblk * 65540].reshape(nblk, 65540)
+    blocks[:, 0] = 0
+    blocks[-1, 0] = 1  # BFINAL
+    blocks[:, 1:3] = 0xFF  # LEN = 65535
+    blocks[:, 3:5] = 0x00  # NLEN
+    step = 4096
+    ad_b = 1
+    for lo in range(0, nblk, step):
+        hi = min(nblk, lo + step)
+        blocks[lo:hi, 5:] = rng.integers(0, 256, size=(hi - lo, 65535), dtype=np.uint8)
+        for r in range(lo, hi):
+            ad_b = zlib.adler32(blocks[r, 5:], ad_b)
+    zb[-4:] = np.frombuffer(struct.pack(">I", ad_b), dtype=np.uint8)
+    len_b = nblk * 65535
+    assert len(zb) > 1 << 32 and len_b > 1 << 32
+    # ---- arenas in HBM
+    a_in = (len(za) + 255) // 256 * 256
+    d_in = torch.empty(a_in + len(zb) + 256, dtype=torch.uint8, device=dev)
+    d_in[:len(za)] = torch.from_numpy(np.frombuffer(za, dtype=np.uint8).copy()).to(dev)
+    d_in[a_in:a_in + len(zb)] = torch.from_numpy(zb).to(dev)
+    a_out = (len_a + 255) // 256 * 256
+    d_out = torch.empty(a_out + len_b + 256, dtype=torch.uint8, device=dev)
+    mk = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)  # noqa: E731
+    d_in_off, d_in_len = mk([0, a_in]), mk([len(za), len(zb)])
+    d_out_off, d_out_cap = mk([0, a_out]), mk([len_a, len_b])
+    d_out_len, d_in_used = mk([0, 0]), mk([0, 0])
+    d_status = torch.full((2,), -1, dtype=torch.int32, device=dev)
+    d_adler = torch.zeros(2, dtype=torch.int32, device=dev)
+    d_detail = torch.zeros(4, dtype=torch.int32, device=dev)
+    unit_t = torch.from_numpy(np.frombuffer(unit, dtype=np.uint8).copy()).to(dev)
+    for ring in (11, 15):
+        d_out.fill_(0xCD)
+        d_status.fill_(-1)
+        torch.cuda.synchronize()
+        gpu_ctx.set_ring_bits(ring)
+        gpu_ctx.decompress_many_device(d_in.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), d_out.data_ptr(), d_out_off.data_ptr(),
+                                       d_out_cap.data_ptr(), d_out_len.data_ptr(), d_status.data_ptr(), d_detail.data_ptr(),
+                                       d_in_used.data_ptr(), d_adler.data_ptr(), 2, sync=True)
+        assert d_status.cpu().tolist() == [0, 0], (ring, d_status.cpu().tolist(), d_detail.cpu().tolist())
+        assert d_out_len.cpu().tolist() == [len_a, len_b], ring
+        assert d_in_used.cpu().tolist() == [len(za), len(zb)], ring
+        assert d_adler.cpu().numpy().view(np.uint32).tolist() == [ad_a, ad_b], ring
+        got_a = d_out[:len_a].view(reps_a, 1 << 20)
+        for lo in range(0, reps_a, 256):
+            assert bool((got_a[lo:lo + 256] == unit_t).all()), (ring, lo)
+        got_b = d_out[a_out:a_out + len_b].view(nblk, 65535)
+        for lo in range(0, nblk, step):
+            hi = min(nblk, lo + step)
+            assert bool(torch.equal(got_b[lo:hi], torch.from_numpy(blocks[lo:hi, 5:].copy()).to(dev))), (ring, lo)
+        assert bool((d_out[len_a:a_out] == 0xCD).all()) and bool((d_out[a_out + len_b:] == 0xCD).all())  # nothing past either extent
+    gpu_ctx.set_ring_bits(11)

@@ -14,7 +14,7 @@ import corpus
 from conftest import REF_CASES, ROOT, read_case
 from test_oracle_golden import load_vectors
 
-RINGS = [15, 13, 12, 11]
+RINGS = [15, 14, 13, 12, 11]  # every shipped instance (pzg_set_option accepts 11..15)
 
 
 class R(C.Structure):
@@ -96,7 +96,7 @@ def test_model_fuzz_valid_and_corrupt(model, oracle, rb):
         assert same(ro, oo, rm, om), (seed, ro.status, rm.status, ro.message)
 
 
-@pytest.mark.parametrize("rb", [13, 12, 11])
+@pytest.mark.parametrize("rb", [14, 13, 12, 11])
 def test_model_far_window_and_small_capacity(model, oracle, rb):
     """Back-references older than the LDS ring come from the flushed output; an output larger than
     its capacity is handed to the 32 KiB-ring pass (the harness does what the fixup launch does)."""
@@ -127,7 +127,7 @@ def test_model_long_codes_second_level_tables(model, oracle, rb):
             assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
 
 
-@pytest.mark.parametrize("rb", [15, 11])
+@pytest.mark.parametrize("rb", [15, 14, 11])
 def test_model_gzip_members(model, oracle, rb):
     """The gzip extension (RFC 1952 header / CRC-32 + ISIZE trailer around the same DEFLATE core): the kernel
     source against the oracle's gzip restatement, valid and corrupted."""
