@@ -411,11 +411,15 @@ def main():
             from pure_zlib_amd.zlib import PinnedArena
             p_in, p_out = PinnedArena(h_in.size), PinnedArena(int(d_out.numel()))
             p_in.a[:] = h_in
-            ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)  # warm the device mirrors
-            p_out.a[:] = 0xCD
-            t0h = time.perf_counter()
-            o_len, o_st, _det, _used, o_ad = ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
-            dtp = time.perf_counter() - t0h
+            for _ in range(2):  # the first call allocates the device mirrors, the second still maps pages of the arenas
+                ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
+            dtp = None
+            for _ in range(2):  # (the better of two timed calls, each over a poisoned output arena)
+                p_out.a[:] = 0xCD
+                t0h = time.perf_counter()
+                o_len, o_st, _det, _used, o_ad = ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
+                dt1 = time.perf_counter() - t0h
+                dtp = dt1 if dtp is None else min(dtp, dt1)
             ok_p = bool((o_st == 0).all() and (o_len == out_cap).all() and (o_ad == exp_adler).all()) if not args.no_verify else None
             if ok_p:
                 for k0 in (0, n // 2, n - 1):

@@ -58,6 +58,14 @@
 #define PZG_MARK(name)
 #endif
 
+// Lab build of the HOST model only (-DPZG_STATS, tests/tools/model_stats.py): event counts of the token loop
+#if defined(PZG_STATS) && !PZG_DEVICE_PASS
+struct PzgStats { unsigned long long v[32]; };
+extern PzgStats pzg_stats;
+#define PZG_STAT(i, n) (pzg_stats.v[i] += (unsigned long long)(n))
+#else
+#define PZG_STAT(i, n) ((void)0)
+#endif
 #ifndef PZG_WALK_UNROLL
 #define PZG_WALK_UNROLL 8
 #endif
@@ -287,17 +295,22 @@ PZG_FN uint32_t crc32_append(uint32_t crc_a, uint32_t crc_b, uint64_t len_b)
 // `pos` is the per-wave bit cursor; dword(i) fetches a wave-uniform dword with v_readlane.
 // Bits are consumed LSB-first (Monad.hs:224-230).
 struct BitReader {
+    // Round 4: consecutive chunks OVERLAP -- `cur` holds 64 dwords but the cursor moves on to the next chunk after
+    // STRIDE = 56 of them, so the 5 dwords a 128-bit window's last lane needs behind the cursor's own (dword 57 + 4 at most)
+    // are always in `cur`: the windows never gather from `nxt` (two scalar instructions per window and a rare path less,
+    // for 14 % more input loads, which the L2 serves).
+    static constexpr uint32_t STRIDE = 56u, STRIDE_BITS = 32u * STRIDE;
     const uint32_t *base;  // 4-byte aligned address at or below the stream start
     uint32_t ndw;          // dwords covering [base, stream end)
     uint32_t mis_bits;     // 8 * (stream start - base)
     uint64_t end_rel;      // mis_bits + 8 * stream length: first bit (relative to base) past the stream
     uint32_t win_end;      // a cursor in a dword below this index has >= 192 stream bits in front of it
     // The cursor is kept as (chunk0, rp): the hot loops only ever touch the 32-bit rp.
-    uint32_t chunk0;       // dword index of the 64-dword chunk the cursor is in (a multiple of 64; lane 0 of `cur`)
-    uint32_t rp;           // next unread bit, relative to bit 32 * chunk0; slide() keeps it below 2048
+    uint32_t chunk0;       // dword index of the 64-dword chunk the cursor is in (a multiple of STRIDE; lane 0 of `cur`)
+    uint32_t rp;           // next unread bit, relative to bit 32 * chunk0; slide() keeps it below STRIDE_BITS
     int32_t rp_ok1, rp_ok2;  // rp below these (signed): a 64-bit / a 128-bit window may run (set_limits)
 #if PZG_DEVICE_PASS
-    uint32_t cur, nxt;     // per-lane: dwords chunk0 + lane and chunk0 + 64 + lane
+    uint32_t cur, nxt;     // per-lane: dwords chunk0 + lane and chunk0 + STRIDE + lane
 #if PZG_DMA_PREFETCH
     // Two chunks ahead: the chunk after `nxt` is fetched straight into LDS (global_load_lds: no VGPR, so no
     // register copy can force a wait for it) and picked up one slide later.
@@ -366,7 +379,7 @@ struct BitReader {
 #if PZG_DEVICE_PASS
         // (the chunk indices pass through an opaque statement: as literal constants, lane + 64 and lane + 128 are computed once
         // in the kernel's prologue and held in two vector registers for its whole life -- or spilled, in the gzip instance)
-        uint32_t c1 = 64u, c2 = 128u;
+        uint32_t c1 = STRIDE, c2 = 2u * STRIDE;
         asm volatile("" : "+s"(c1), "+s"(c2));
         cur = load_chunk(0u);
         nxt = load_chunk_raw(c1);  // masked when it becomes `cur`
@@ -376,11 +389,11 @@ struct BitReader {
 #endif
     }
 
-    // wave-uniform dword i; on the device i must lie in [chunk0, chunk0 + 128)
+    // wave-uniform dword i; on the device i must lie in [chunk0, chunk0 + STRIDE + 64)
     PZG_FN uint32_t dword(uint32_t i) const
     {
 #if PZG_DEVICE_PASS
-        const uint32_t a = read_lane(cur, i & 63u), b = read_lane(nxt, i & 63u);
+        const uint32_t a = read_lane(cur, (i - chunk0) & 63u), b = read_lane(nxt, (i - chunk0 - STRIDE) & 63u);
         return (i - chunk0) < 64u ? a : i < ndw ? b : 0u;
 #else
         return load_dw(i);
@@ -390,15 +403,15 @@ struct BitReader {
     // one chunk forward
     PZG_FN void step_chunk()
     {
-        rp -= 2048u;
-        chunk0 += 64u;
+        rp -= STRIDE_BITS;
+        chunk0 += STRIDE;
 #if PZG_DEVICE_PASS
         cur = zero_past_end(nxt, chunk0);
 #if PZG_DMA_PREFETCH
         nxt = take_prefetch();
-        dma_prefetch(chunk0 + 128u);
+        dma_prefetch(chunk0 + 2u * STRIDE);
 #else
-        nxt = load_chunk_raw(chunk0 + 64u);
+        nxt = load_chunk_raw(chunk0 + STRIDE);
 #endif
 #endif
         set_limits();
@@ -406,7 +419,7 @@ struct BitReader {
     // keep the cursor's dword inside `cur`
     PZG_FN void slide()
     {
-        while (rp >= 2048u) step_chunk();
+        while (rp >= STRIDE_BITS) step_chunk();
     }
 
     PZG_FN int64_t avail() const { return (int64_t)end_rel - (int64_t)pos(); }
@@ -426,12 +439,12 @@ struct BitReader {
         rp += n;
         slide();
     }
-    // drop() for n < 2048 from a cursor slide() has already placed: at most one chunk step, written
+    // drop() for n < STRIDE_BITS from a cursor slide() has already placed: at most one chunk step, written
     // without a loop so the prefetch into `nxt` stays an outstanding load (no copy of it is needed).
     PZG_FN void drop_short(uint32_t n)
     {
         rp += n;
-        if (__builtin_expect(rp >= 2048u, 0)) step_chunk();
+        if (__builtin_expect(rp >= STRIDE_BITS, 0)) step_chunk();
     }
     PZG_FN void align_to_byte() { drop((8u - (rp & 7u)) & 7u); }  // (32 * chunk0 is a multiple of 8)
 };
@@ -988,6 +1001,9 @@ struct Decoder {
             if (TREE == TREE_LITLEN) {
                 lit_sub_used = sub_total;
                 use_sub = np_fit >= SUB_MIN_PREFIXES ? 1u : 0u;
+#if defined(PZG_STATS) && defined(PZG_STATS_NOSUB) && !PZG_DEVICE_PASS
+                use_sub = 0u;  // (lab statistics: how many tokens need the second level at all)
+#endif
             }
 #pragma nounroll
             for (uint32_t i0 = 0; i0 < sub_total; i0 += PZG_WAVE) {
@@ -1315,9 +1331,11 @@ struct Decoder {
         const uint32_t en = e >> 8, dn = d >> 8;              // [4:0] = code bits
         const uint32_t xl = ubfe(t.w_lo, en, e - en);         // length extra bits:   width = (n + extra) - n  (mod 32)
         const uint32_t xd = ubfe(t.w2, dn, d - dn);           // distance extra bits
-        const uint32_t tk_match = hi_halves(e, d) + ((xl << 16) + xd);  // TK_MATCH | (base len + xl) << 16 | (base dist + xd): no carries
         const uint32_t m = (uint32_t)((int32_t)e >> 31);      // all ones: a length entry, the distance entry counts
-        tb = (e & 0xffu) + ((d & m) & 0xffu);                 // byte sum (one SDWA add): either stop bit (0x80) makes it >= 128
+        // (round 4, by the measured issue costs -- profiles/r04_issue_ports.txt: a shift left, a three-operand add and anything with
+        // a scalar operand are half-rate, a plain and / add of two registers is full-rate)
+        const uint32_t tk_match = hi_halves(e, d) + shl16_add(xl, xd);  // TK_MATCH | (base len + xl) << 16 | (base dist + xd): no carries
+        tb = byte0_sum(e, d & m);                             // byte sum (one SDWA add): either stop bit (0x80) makes it >= 128
         tk = bit_select(m, tk_match, e);
     }
     template <bool FX>
@@ -1330,14 +1348,15 @@ struct Decoder {
         spec_finish(t, tb, tk);
     }
     // two independent decodes, stage by stage
-    template <bool FX>
+    // SUB: 1 = the block's code has second-level tables, 0 = it has none, -1 = look at use_sub (the general paths)
+    template <bool FX, int SUB = -1>
     PZG_FN void decode_pair(uint32_t lo0, uint32_t mid0, uint32_t hi0, uint32_t mid1, uint32_t hi1, uint32_t r, uint32_t &tb0,
                             uint32_t &tk0, uint32_t &tb1, uint32_t &tk1)
     {
         Spec a, b;
         spec_bits<FX>(a, lo0, mid0, hi0, r);
         spec_bits<FX>(b, hi0, mid1, hi1, r);
-        if (!FX && use_sub) {  // wave-uniform
+        if (!FX && (SUB < 0 ? use_sub != 0u : SUB != 0)) {  // wave-uniform
             uint32_t ea = spec_sub_load(a), eb = spec_sub_load(b);  // (both lookups in flight together)
 #if PZG_DEVICE_PASS
             asm("" : "+v"(ea), "+v"(eb));
@@ -1477,42 +1496,30 @@ struct Decoder {
     // decoded from stream bits alone (a prefix code is settled by its own bits, whatever follows them); any other is made
     // a stopper, so the walk ends in front of it and token_step_checked() finds what the reference finds there
     // (the end-of-block code as a rule; a truncated stream otherwise).
-    template <bool FX, bool TAIL = false>
+    template <bool FX, bool TAIL = false, int SUB = -1>
     PZG_FN void window2_decode(LaneVec<uint32_t> &TB0, LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TB1, LaneVec<uint32_t> &TK1)
     {
         PZG_MARK("w2.begin");
 #if PZG_DEVICE_PASS
         {
-            // lane k's first token starts at bit p = rp + k of the chunk: dword d = p >> 5 (the window's dwords sit in `cur`,
-            // or in `cur` and `nxt`), bit r = p & 31 of it.  The crossbar takes a byte address and ignores its low two bits
+            // lane k's first token starts at bit p = rp + k of the chunk: dword d = p >> 5 (the window's dwords all sit in `cur`:
+            // chunks overlap, see BitReader), bit r = p & 31 of it.  The crossbar takes a byte address and ignores its low two bits
             // (lane = address[7:2]) and the funnel shift its amount's high bits, so p >> 3 and p themselves will do.
-            const uint32_t li = br.rp >> 5;
-            const uint32_t r = br.rp + lane_id(), a = r >> 3, d = r >> 5;
+            static_assert((BitReader::STRIDE_BITS + 62u) / 32u + 4u <= 63u, "the last lane's fifth dword lies in `cur`");
+            const uint32_t r = br.rp + lane_id(), a = r >> 3;
             uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)a, (int)br.cur);
             uint32_t mid0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 4u), (int)br.cur);
             uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 8u), (int)br.cur);
             uint32_t mid1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 12u), (int)br.cur);
             uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a + 16u), (int)br.cur);
-            if (__builtin_expect(li > 56u, 0)) {  // (one window in nine) the same gathers from the next chunk for the dwords past this one
-                const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)br.nxt);
-                const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 1u) << 2), (int)br.nxt);
-                const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 2u) << 2), (int)br.nxt);
-                const uint32_t n3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 3u) << 2), (int)br.nxt);
-                const uint32_t n4 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d + 4u) << 2), (int)br.nxt);
-                lo0 = d >= 64u ? n0 : lo0;  // (the crossbar index wraps modulo 64, so dword d of `nxt` is lane d - 64)
-                mid0 = d + 1u >= 64u ? n1 : mid0;
-                hi0 = d + 2u >= 64u ? n2 : hi0;
-                mid1 = d + 3u >= 64u ? n3 : mid1;
-                hi1 = d + 4u >= 64u ? n4 : hi1;
-            }
-            decode_pair<FX>(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
+            decode_pair<FX, SUB>(lo0, mid0, hi0, mid1, hi1, r, TB0.v, TK0.v, TB1.v, TK1.v);
         }
 #else
         {
             const uint32_t i0 = br.chunk0 + (br.rp >> 5), boff = br.rp & 31u;
             PZG_LANES_BEGIN(k)
                 const uint32_t q = boff + k, d0 = i0 + (q >> 5), r = q & 31u;
-                decode_pair<FX>(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
+                decode_pair<FX, SUB>(br.dword(d0), br.dword(d0 + 1u), br.dword(d0 + 2u), br.dword(d0 + 3u), br.dword(d0 + 4u), r,
                             PZG_LV(TB0, k), PZG_LV(TK0, k), PZG_LV(TB1, k), PZG_LV(TK1, k));
             PZG_LANES_END
         }
@@ -1716,6 +1723,7 @@ struct Decoder {
         const uint32_t hist = (op_hi | (op32 >> 20)) ? 0x100000u : op32 + (RING_BITS == 15 ? hist_extra : 0u);
         LaneVec<uint32_t> INCL, START;
         LaneVec<bool> BIG, MATCH, SRC_IN, SRC_OUT;
+        const uint64_t waiting = bit_field_mask(qn, 0u);  // lanes 0 .. qn - 1 (qn <= 63)
         PZG_LANES_BEGIN(t)
             PZG_LV(INCL, t) = t < qn ? ((PZG_LV(QT, t) >> 16) & 511u) : 0u;
         PZG_LANES_END
@@ -1730,13 +1738,25 @@ struct Decoder {
             PZG_LV(SRC_OUT, t) = dist > hist + start;     // ... or lies before the output (an error: found when it heads a segment)
         PZG_LANES_END
         // (four compares, the rest on the masks: scalar instructions instead of select / or / compare chains per lane)
-        const uint64_t waiting = (1ull << qn) - 1ull;  // qn <= 63
         const uint64_t stopmask =
             waiting & (lanes_ballot(BIG) | (lanes_ballot(MATCH) & (lanes_ballot(SRC_IN) | lanes_ballot(SRC_OUT))));
         uint32_t v = stopmask ? ctz64(stopmask) : qn;  // tokens of this segment
+#if defined(PZG_STATS) && !PZG_DEVICE_PASS
+        PZG_STAT(2, 1);  // segments (FAST and general)
+        PZG_STAT(3, FAST ? 1 : 0);
+        if (stopmask) {
+            const uint64_t first = stopmask & (0ull - stopmask);
+            PZG_STAT(4, (first & lanes_ballot(BIG)) ? 1 : 0);  // ended by the 128-byte limit
+            PZG_STAT(5, (!(first & lanes_ballot(BIG)) && (first & lanes_ballot(SRC_IN))) ? 1 : 0);  // ... by a source inside the segment
+        } else {
+            PZG_STAT(6, 1);  // the queue ran out
+        }
+        PZG_STAT(7, qn);
+#endif
         PZG_MARK("e.v");
         PZG_ACCW(9, t_b);
         if (__builtin_expect(v == 0u, 0)) {
+            PZG_STAT(11, 1);  // a head token for copy_match (or a bail-out of the fast body)
             if (FAST) return EMIT_BAIL;
             const uint32_t tk = lane_get(QT, 0u), dist = tk & 0xffffu, len = (tk >> 16) & 511u;
             if ((uint64_t)dist > op + (RING_BITS == 15 ? hist_extra : 0u)) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
@@ -1753,6 +1773,9 @@ struct Decoder {
 #endif
             PZG_T0(t_d);
             const uint32_t run = lane_get(INCL, v - 1u);
+            PZG_STAT(8, run);   // bytes of non-degenerate segments
+            PZG_STAT(9, v);     // their tokens
+            PZG_STAT(10, run > 64u ? 1 : 0);
             if (run == v) {
                 // one byte per token: nothing but literals (a match is three bytes or more).  Byte j IS token j's byte:
                 // no announcements, no gathers -- literal-heavy data (little or no redundancy) spends its time here.
@@ -1867,8 +1890,10 @@ struct Decoder {
     // tests; (2) a uniform value the register allocator parks in a vector register (the scalar file is full here) makes its
     // compare a vector compare and the branch, and with it the whole region, divergent for the structurizer: pass such
     // operands through uni() at the compare, as window2_ok() does.
+    // Round 4: the loop exists once per kind of block -- fixed code, dynamic code with and without second-level tables
+    // (SUB) -- so that the windows test nothing about the block: two scalar instructions per window less.
     enum : uint32_t { HL_GENERAL = 1, HL_WINDOW = 2 };
-    template <bool FX>
+    template <bool FX, int SUB>
     PZG_FN uint32_t hot_loop(LaneVec<uint32_t> &TK0, LaneVec<uint32_t> &TK1, uint64_t &S0, uint64_t &S1, uint32_t &k0, uint32_t &k1)
     {
         uint32_t why;
@@ -1884,10 +1909,11 @@ struct Decoder {
                     break;
                 }
                 LaneVec<uint32_t> TB0, TB1;
-                window2_decode<FX>(TB0, TK0, TB1, TK1);
+                window2_decode<FX, false, SUB>(TB0, TK0, TB1, TK1);
                 S0 = 0;
                 S1 = 0;
                 k1 = 0;
+                PZG_STAT(0, 1);  // windows decoded by the hot loop
                 k0 = walk_half(TB0, 0u, S0);
                 why = HL_WINDOW;
                 if (__builtin_expect(k0 >= 64u, 0)) break;
@@ -1895,6 +1921,7 @@ struct Decoder {
                 if (__builtin_expect(k1 >= 64u, 0)) break;
                 const uint32_t nt0 = popc64(S0), nt1 = popc64(S1);
                 if (__builtin_expect((qn + nt0) + nt1 > QCAP, 0)) break;
+                PZG_STAT(1, nt0 + nt1);  // tokens queued by clean windows
                 queue_append(TK0, S0, nt0, TK1, S1, nt1);
                 br.drop_short(k1 + 128u);
                 continue;
@@ -1920,7 +1947,8 @@ struct Decoder {
             LaneVec<uint32_t> TK0, TK1;
             uint64_t S0 = 0, S1 = 0;
             uint32_t k0 = 0, k1 = 0;
-            if (!RES) why = hot_loop<FX>(TK0, TK1, S0, S1, k0, k1);
+            if (!RES) why = FX ? hot_loop<FX, 0>(TK0, TK1, S0, S1, k0, k1) : use_sub ? hot_loop<FX, 1>(TK0, TK1, S0, S1, k0, k1)
+                                                                                       : hot_loop<FX, 0>(TK0, TK1, S0, S1, k0, k1);
             if (why == HL_WINDOW) checked = window2_rare(TK0, TK1, S0, S1, k0, k1);
             else checked = qn < QHIGH && fill_queue<FX>();
             PZG_ACC(4, tw);
@@ -1933,6 +1961,7 @@ struct Decoder {
             }
             PZG_T0(tc);
             const int st = token_step_checked<FX>();
+            PZG_STAT(12, 1);  // checked steps
             PZG_ACC(5, tc);
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
             prof[15] += 1;

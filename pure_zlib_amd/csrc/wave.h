@@ -245,6 +245,19 @@ PZG_FN uint32_t mask_select(uint64_t m, uint32_t k, uint32_t a, uint32_t b)
 #endif
 }
 
+// bit k of the wave-uniform mask m ? a : 0 (the zero rides in the instruction: no register holds it)
+PZG_FN uint32_t mask_keep(uint64_t m, uint32_t k, uint32_t a)
+{
+#if PZG_DEVICE_PASS
+    (void)k;
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m));
+    return r;
+#else
+    return ((m >> k) & 1ull) ? a : 0u;
+#endif
+}
+
 // m1 ? a1 : m0 ? a0 : b -- two selects in ONE statement, so that both a0 and a1 (crossbar results, typically) are asked
 // for before either is waited for
 PZG_FN uint32_t mask_select2(uint64_t m0, uint64_t m1, uint32_t k, uint32_t a0, uint32_t a1, uint32_t b)
@@ -319,6 +332,30 @@ PZG_FN uint32_t ubfe(uint32_t x, uint32_t off, uint32_t width)
     off &= 31u;
     width &= 31u;
     return (x >> off) & ((1u << width) - 1u);
+#endif
+}
+
+// (a & 0xff) + (b & 0xff) as ONE instruction (SDWA: both operands' low bytes selected in the add itself)
+PZG_FN uint32_t byte0_sum(uint32_t a, uint32_t b)
+{
+#if PZG_DEVICE_PASS
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return (a & 0xffu) + (b & 0xffu);
+#endif
+}
+
+// (x << 16) + y as ONE instruction (v_lshl_add_u32)
+PZG_FN uint32_t shl16_add(uint32_t x, uint32_t y)
+{
+#if PZG_DEVICE_PASS
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#else
+    return (x << 16) + y;
 #endif
 }
 

@@ -183,6 +183,32 @@ inline Either apply_chunk_rule(const LazyByteString &chunks, uint64_t in_used, B
     return Either::Right(std::move(data));
 }
 
+namespace detail {
+// The mirrors' page-locked arenas (include/pzg.h PZG_HOST_PINNED): one input and one output buffer per thread from
+// pzg_host_alloc, grow-only.  A batch is packed straight into them, so the library stages nothing a second time and the
+// copy engines read / write the caller's memory at link speed.  Where the system will not lock the memory the call goes
+// through ordinary vectors and the staged path: same results.
+struct PinnedArena {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    ~PinnedArena() { pzg_host_free(p); }
+    uint8_t *reserve(size_t bytes)
+    {
+        if (cap >= bytes) return p;
+        pzg_host_free(p);
+        cap = bytes + bytes / 4 < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
+        p = (uint8_t *)pzg_host_alloc(cap);
+        if (!p) cap = 0;
+        return p;
+    }
+};
+inline PinnedArena &arena(int which)
+{
+    static thread_local PinnedArena a[2];
+    return a[which];
+}
+}  // namespace detail
+
 // decompressMany: every stream decoded by its own wavefront in one launch.  zlib streams do not carry
 // their decoded size, so each stream gets a capacity (size_hint[i], or a guess) and the streams that
 // report PZG_E_OUT_TOO_SMALL are relaunched once with the exact size the kernel measured.
@@ -213,18 +239,27 @@ inline std::vector<Either> decompressMany(const std::vector<LazyByteString> &inp
             ipos += detail::align16(in_len[k]);
             opos += detail::align16(out_cap[k]);
         }
-        std::vector<uint8_t> in_buf(ipos + 16), out_buf(opos + 16);
+        // packed at ascending offsets into the thread's page-locked arenas (PZG_HOST_PINNED); pageable vectors if those are refused
+        uint8_t *in_p = detail::arena(0).reserve(ipos + 16), *out_p = detail::arena(1).reserve(opos + 16);
+        const bool pinned = in_p && out_p;
+        std::vector<uint8_t> in_vec, out_vec;
+        if (!pinned) {
+            in_vec.resize(ipos + 16);
+            out_vec.resize(opos + 16);
+            in_p = in_vec.data();
+            out_p = out_vec.data();
+        }
         for (size_t k = 0; k < m; ++k)
-            if (in_len[k]) memcpy(in_buf.data() + in_off[k], flat[todo[k]].data(), in_len[k]);
-        int rc = pzg_decompress_many(ctx.handle(), in_buf.data(), in_off.data(), in_len.data(), out_buf.data(), out_off.data(),
+            if (in_len[k]) memcpy(in_p + in_off[k], flat[todo[k]].data(), in_len[k]);
+        int rc = pzg_decompress_many(ctx.handle(), in_p, in_off.data(), in_len.data(), out_p, out_off.data(),
                                      out_cap.data(), out_len.data(), status.data(), det.data(), in_used.data(), adler.data(),
-                                     (uint32_t)m, 0);
+                                     (uint32_t)m, pinned ? PZG_HOST_PINNED : 0u);
         if (rc != PZG_RC_OK) throw std::runtime_error(std::string("pzg_decompress_many: ") + pzg_last_error(ctx.handle()));
         std::vector<size_t> retry;
         for (size_t k = 0; k < m; ++k) {
             const size_t i = todo[k];
             if (status[k] == PZG_OK) {
-                results[i] = apply_chunk_rule(inputs[i], in_used[k], ByteString((const char *)out_buf.data() + out_off[k], out_len[k]));
+                results[i] = apply_chunk_rule(inputs[i], in_used[k], ByteString((const char *)out_p + out_off[k], out_len[k]));
             } else if (status[k] == PZG_E_OUT_TOO_SMALL && attempt == 0) {
                 caps[i] = out_len[k];
                 retry.push_back(i);

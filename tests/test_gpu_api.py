@@ -395,7 +395,9 @@ def test_host_pinned_arenas(gpu_ctx, oracle):
                 for x, y in zip(ref, got):
                     assert np.array_equal(x, y)
                 assert got[1][7] == 1 and got[1][n - 5] == 14 and int((got[1] == 0).sum()) == n - 2
-                for k in range(n):
+                for k in range(n):  # (a failed stream's bytes are unspecified: only what it produced before the error was flushed)
+                    if got[1][k] not in (0, 14):
+                        continue
                     nb = int(min(got[0][k], out_cap[k]))
                     lo = int(out_off[k])
                     assert np.array_equal(a_out.a[lo:lo + nb], ref_out[lo:lo + nb]), k

@@ -73,15 +73,19 @@ enum Pat {
     P_DSREAD_U8,
     P_DSPERMUTE,
     P_WALK2,
+    P_CMP_4CND,
+    P_SOR_CND_MIX,
+    P_SOR_CND64_MIX,
+    P_VCMP_CND_FAR,
     P_COUNT
 };
 static const char *pat_name[P_COUNT] = {"valu_e32(4B,indep)", "valu_vop3 alignbit(8B)", "valu_sdwa", "valu_dpp row_shr", "v_readlane->s",
                                         "v_cndmask sgpr-mask", "v_cmp->sgpr", "salu s_add(indep)", "s_bitset1_b64", "s_cmp+cbranch(not taken)",
                                         "s_branch(taken,next)", "walk step x4 (nt)", "mix 1 valu+1 salu", "ds_bpermute", "ds_read_b32",
                                         "ds_write_b8", "s_nop 0", "s_waitcnt lgkm(0)", "valu_e32 dependent", "salu dependent", "mix 2 valu+1 salu",
-                                        "walk step, exit taken/8", "vop2 e32 + literal(8B)", "vop1 v_mov e32", "v_mbcnt_lo (vop3)", "v_add_u32_e64 (vop3,2op)", "v_lshl_add_u32", "v_cmp e32 -> vcc", "v_cndmask e32 (vcc)", "s_add + literal(8B)", "s_addk (sopk)", "s_and_b64/s_bcnt1_b64", "mix 1 e32 + 1 vop3", "mix 1 vop3 + 1 salu", "v_bfe_u32 (vop3)", "v_cmp_e32+v_cndmask_e32", "v_cndmask_e64 vcc", "v_cndmask_e32 (vcc set once)", "v_cmp_e64+v_cndmask_e64 sgpr", "v_bitop3_b32", "v_lshlrev_b32_e32 const", "v_perm_b32 sgpr sel", "ds_read_u8", "ds_permute", "walk step, 26 bits/token"};
+                                        "walk step, exit taken/8", "vop2 e32 + literal(8B)", "vop1 v_mov e32", "v_mbcnt_lo (vop3)", "v_add_u32_e64 (vop3,2op)", "v_lshl_add_u32", "v_cmp e32 -> vcc", "v_cndmask e32 (vcc)", "s_add + literal(8B)", "s_addk (sopk)", "s_and_b64/s_bcnt1_b64", "mix 1 e32 + 1 vop3", "mix 1 vop3 + 1 salu", "v_bfe_u32 (vop3)", "v_cmp_e32+v_cndmask_e32", "v_cndmask_e64 vcc", "v_cndmask_e32 (vcc set once)", "v_cmp_e64+v_cndmask_e64 sgpr", "v_bitop3_b32", "v_lshlrev_b32_e32 const", "v_perm_b32 sgpr sel", "ds_read_u8", "ds_permute", "walk step, 26 bits/token", "1 v_cmp_e32 + 4 v_cndmask_e32", "s_or vcc + cndmask_e32 + 6 valu", "s_or sgpr + cndmask_e64 + 6 valu", "v_cmp_e32, 6 valu, cndmask_e32"};
 // instructions per group (for the rate)
-static const int pat_insts[P_COUNT] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 1, 4, 2, 1, 1, 1, 4, 1, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 2, 4, 2, 4, 4, 2, 4, 4, 4, 1, 1, 4};
+static const int pat_insts[P_COUNT] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 1, 4, 2, 1, 1, 1, 4, 1, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 2, 4, 2, 4, 4, 2, 4, 4, 4, 1, 1, 4, 5, 8, 8, 8};
 
 template <int PAT>
 __global__ void __launch_bounds__(64) bench_kernel(uint32_t iters, uint64_t *out, uint32_t seed)
@@ -243,6 +247,26 @@ __global__ void __launch_bounds__(64) bench_kernel(uint32_t iters, uint64_t *out
                 s0 += kb;
             }
         }
+
+        if (PAT == P_CMP_4CND)
+            asm volatile(".rept " STR(REPT) "\n\tv_cmp_lt_u32_e32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\tv_cndmask_b32_e32 %3, %3, %4, vcc\n\t"
+                         "v_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\t.endr"
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(v4) : "vcc");
+        if (PAT == P_SOR_CND_MIX)   // what the emit code does: a mask formed on the scalar unit into vcc, one select, other vector work around it
+            asm volatile(".rept " STR(REPT) "\n\ts_or_b64 vcc, %5, %6\n\tv_add_u32_e32 %0, %4, %0\n\tv_add_u32_e32 %1, %4, %1\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\t"
+                         "v_add_u32_e32 %3, %4, %3\n\tv_add_u32_e32 %0, %4, %0\n\tv_add_u32_e32 %1, %4, %1\n\tv_add_u32_e32 %3, %4, %3\n\t.endr"
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(v4), "s"(m), "s"(m2) : "vcc", "scc");
+        if (PAT == P_SOR_CND64_MIX) {
+            uint64_t mm = 0;
+            asm volatile(".rept " STR(REPT) "\n\ts_or_b64 %4, %6, %7\n\tv_add_u32_e32 %0, %5, %0\n\tv_add_u32_e32 %1, %5, %1\n\tv_cndmask_b32_e64 %2, %2, %5, %4\n\t"
+                         "v_add_u32_e32 %3, %5, %3\n\tv_add_u32_e32 %0, %5, %0\n\tv_add_u32_e32 %1, %5, %1\n\tv_add_u32_e32 %3, %5, %3\n\t.endr"
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(mm) : "v"(v4), "s"(m), "s"(m2) : "scc");
+            s0 += (uint32_t)mm;
+        }
+        if (PAT == P_VCMP_CND_FAR)
+            asm volatile(".rept " STR(REPT) "\n\tv_cmp_lt_u32_e32 vcc, %0, %1\n\tv_add_u32_e32 %0, %4, %0\n\tv_add_u32_e32 %1, %4, %1\n\tv_add_u32_e32 %3, %4, %3\n\t"
+                         "v_add_u32_e32 %0, %4, %0\n\tv_add_u32_e32 %1, %4, %1\n\tv_add_u32_e32 %3, %4, %3\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\t.endr"
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(v4) : "vcc");
         if (PAT == P_NOP) asm volatile(".rept " STR(REPT) "\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t.endr");
         if (PAT == P_WAIT) asm volatile(".rept " STR(REPT) "\n\ts_waitcnt lgkmcnt(0)\n\t.endr");
     }
@@ -282,7 +306,7 @@ int main(int argc, char **argv)
     printf("%-28s", "pattern \\ waves per CU");
     for (int W : Ws) printf(" %13d", W);
     printf("   (instructions per CU-cycle; last column: MHz)\n");
-    for (int p = 0; p < P_COUNT; ++p) {
+    for (int p = argc > 2 ? P_COUNT - atoi(argv[2]) : 0; p < P_COUNT; ++p) {  // (argv[2] = n: only the last n patterns)
         printf("%-28s", pat_name[p]);
         double mhz = 0;
         for (int W : Ws) {

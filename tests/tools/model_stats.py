@@ -1,0 +1,70 @@
+"""Lab tool: event counts of the token loop (windows, segments and why they end, bytes per segment, checked steps) from the
+HOST model of the kernel source built with -DPZG_STATS, over a workload of bench.py.  Usage:
+    python tests/tools/model_stats.py [l6_32k|fixed_4k|html|skewed_bytes] [count]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import zlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import corpus  # noqa: E402
+
+NAMES = ["windows (hot loop)", "tokens queued by clean windows", "segments", "segments in the fast body", "ended by the 128-byte limit",
+         "ended by a source inside the segment", "ended by the queue running out", "sum of qn at segment start", "bytes of segments",
+         "tokens of segments", "segments with a second pass", "head token for copy_match / bail", "checked steps"]
+
+
+def build():
+    d = os.path.join(ROOT, "tests", "model")
+    so = os.path.join(d, "libpzgmodel_stats.so")
+    extra = os.path.join(ROOT, "build", "model_stats_glue.cpp")
+    os.makedirs(os.path.dirname(extra), exist_ok=True)
+    with open(extra, "w") as f:
+        f.write('#include "%s"\nPzgStats pzg_stats;\nextern "C" unsigned long long *pzm_stats(void) { return pzg_stats.v; }\n' % os.path.join(d, "model_harness.cpp"))
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-DPZG_STATS", *os.environ.get("PZG_MODEL_FLAGS", "").split(), "-o", so, extra])
+    return C.CDLL(so)
+
+
+class R(C.Structure):
+    _fields_ = [("status", C.c_int32), ("detail0", C.c_uint32), ("detail1", C.c_uint32), ("adler", C.c_uint32),
+                ("out_len", C.c_uint64), ("in_used", C.c_uint64)]
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "l6_32k"
+    cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    M = build()
+    M.pzm_stats.restype = C.POINTER(C.c_ulonglong)
+    M.pzm_decompress.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(R)]
+    tot_out = tot_in = 0
+    for seed in range(cnt):
+        if wl == "fixed_4k":
+            t = corpus.zipf_text(4096, seed)
+            co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+            z = co.compress(t) + co.flush()
+        elif wl == "html":
+            t = corpus.html_slice(32768, seed)
+            z = zlib.compress(t, 6)
+        elif wl == "skewed_bytes":
+            t = corpus.skewed_bytes(32768, seed)
+            z = zlib.compress(t, 6)
+        else:
+            t = corpus.zipf_text(32768, seed)
+            z = zlib.compress(t, 6)
+        out = C.create_string_buffer(len(t))
+        r = R()
+        assert M.pzm_decompress(z, len(z), out, len(t), 11, C.byref(r)) == 0 and r.status == 0 and out.raw == t
+        tot_out += len(t)
+        tot_in += len(z)
+    v = M.pzm_stats()
+    print(f"{wl}: {cnt} streams, {tot_in} B in, {tot_out} B out, per stream:")
+    for i, n in enumerate(NAMES):
+        print(f"  {n:42s} {v[i] / cnt:10.1f}")
+    print(f"  bits per window {8 * tot_in / max(v[0], 1):.1f}; tokens per window {v[1] / max(v[0], 1):.2f}; bytes per segment {v[8] / max(v[2] - v[11], 1):.1f}; "
+          f"tokens per segment {v[9] / max(v[2] - v[11], 1):.1f}; qn at segment start {v[7] / max(v[2], 1):.1f}")
+
+
+if __name__ == "__main__":
+    main()

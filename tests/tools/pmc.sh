@@ -9,7 +9,7 @@ out=$root/gpurun_out; mkdir -p $out; : > $out/pmc_summary.txt
 i=0
 for grp in "$@"; do
   i=$((i+1)); d=/tmp/pmc_$i; rm -rf $d
-  timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-ab --no-host-path --cpu-sample 0 --adler-gib 0 --ring-bits $rb > $d.log 2>&1
+  timeout 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -o p -- python3 $root/bench.py --steps 3 --warmup 1 --no-ab --no-host-path --no-variants --cpu-sample 0 --adler-gib 0 --ring-bits $rb > $d.log 2>&1
   f=$(find $d -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then echo "group $grp: no csv"; grep -v simple_timer $d.log | tail -8; find $d | head; continue; fi >> $out/pmc_summary.txt
   python3 - "$f" "$grp" >> $out/pmc_summary.txt <<'PY'

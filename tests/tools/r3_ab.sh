@@ -5,7 +5,7 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 out=$root/gpurun_out/${2:-ab}.txt; mkdir -p $root/gpurun_out; : > $out
 run() { # tag, label, args...
   tag=$1; label=$2; shift 2
-  PZG_LIB=$root/build/exp/libpzg_$tag.so timeout 300 python3 $root/bench.py --steps 8 --warmup 2 --no-ab --no-host-path --cpu-sample 0 --adler-gib 0 "$@" 2>/dev/null | tail -1 |
+  PZG_LIB=$root/build/exp/libpzg_$tag.so timeout 300 python3 $root/bench.py --steps 8 --warmup 2 --no-ab --no-host-path --no-variants --cpu-sample 0 --adler-gib 0 "$@" 2>/dev/null | tail -1 |
     python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', '$label', d['value'], d['bit_exact'])" >> $out
 }
 for rep in $(seq 1 ${REPS:-2}); do
