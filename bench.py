@@ -411,19 +411,21 @@ def main():
             from pure_zlib_amd.zlib import PinnedArena
             p_in, p_out = PinnedArena(h_in.size), PinnedArena(int(d_out.numel()))
             p_in.a[:] = h_in
-            for _ in range(2):  # the first call allocates the device mirrors, the second still maps pages of the arenas
-                ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
+            ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)  # allocates the device mirrors
+            p_out.a[:] = 0xCD  # poisoned, then a call whose results are verified ...
+            o_len, o_st, _det, _used, o_ad = ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
+            ok_p = bool((o_st == 0).all() and (o_len == out_cap).all() and (o_ad == exp_adler).all()) if not args.no_verify else None
+            if ok_p:
+                for k0 in range(0, n, max(1, n // 64)):
+                    ok_p = ok_p and p_out.a[int(out_off[k0]):int(out_off[k0]) + int(out_cap[k0])].tobytes() == texts[pick[k0]]
             dtp = None
-            for _ in range(2):  # (the better of two timed calls, each over a poisoned output arena)
-                p_out.a[:] = 0xCD
+            for _ in range(2):  # ... then two timed ones over the arena as it stands (freshly CPU-written lines slow the copy engine's writes down)
                 t0h = time.perf_counter()
                 o_len, o_st, _det, _used, o_ad = ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
                 dt1 = time.perf_counter() - t0h
                 dtp = dt1 if dtp is None else min(dtp, dt1)
-            ok_p = bool((o_st == 0).all() and (o_len == out_cap).all() and (o_ad == exp_adler).all()) if not args.no_verify else None
-            if ok_p:
-                for k0 in (0, n // 2, n - 1):
-                    ok_p = ok_p and p_out.a[int(out_off[k0]):int(out_off[k0]) + int(out_cap[k0])].tobytes() == texts[pick[k0]]
+                if ok_p is not None:
+                    ok_p = ok_p and bool((o_st == 0).all() and (o_ad == exp_adler).all())
             result["host_buffers_variant"]["pinned"] = {
                 "GiBps": round(int(out_cap.sum()) / dtp / 2**30, 2), "ms": round(dtp * 1e3, 1), "ok": ok_p,
                 "note": "the same batch in page-locked arenas (pzg_host_alloc) with PZG_HOST_PINNED: PCIe both ways + kernel, no staging copy",

@@ -256,8 +256,10 @@ PZG_API int pzg_decompress_many_dict(pzg_ctx *ctx,
  *                PZG_OK publishes the remainder as the last one (finalize, Monad.hs:349-353).
  * Host pointers only.  Nothing is re-decoded: a feed costs what its new input costs.
  * Footprint: a pzg_decoder keeps, grow-only until pzg_decoder_destroy, staging of the largest feed it has seen --
- * m x (in_len + 32) + m x out_cap bytes of page-locked host memory and as much device memory -- plus ~37 KiB of device
- * state per decoder.  Where the system will not lock that much the staging falls back to pageable memory (slower copies,
+ * m x (in_len + 32) + m x out_cap bytes of page-locked host memory and as much device memory -- plus ~41 KiB of device
+ * state per decoder (its registers and tables, an 8 KiB image of its wave's LDS, and the last 32 KiB it produced).  A feed
+ * of 512 decoders or more that moves 64 MiB or more is pipelined in ranges (upload, launch, download and the host-side
+ * copies of neighbouring ranges overlap).  Where the system will not lock that much the staging falls back to pageable memory (slower copies,
  * same results).
  */
 typedef struct pzg_decoder pzg_decoder;

@@ -66,6 +66,9 @@ extern PzgStats pzg_stats;
 #else
 #define PZG_STAT(i, n) ((void)0)
 #endif
+#ifndef PZG_RES_HOT_LOOP
+#define PZG_RES_HOT_LOOP 1
+#endif
 #ifndef PZG_WALK_UNROLL
 #define PZG_WALK_UNROLL 8
 #endif
@@ -264,6 +267,14 @@ struct ResumeState {
     uint32_t detail0, detail1, pad;
     uint64_t in_total;     // input bytes consumed by the earlier calls (positions in error details count from the stream start)
     uint32_t QT[64];
+};
+
+// A suspended decoder's slot in HBM: ResumeState | the wave's LDS image | (small rings) its 32 KiB history.
+template <int RING_BITS>
+struct ResumeSlot {
+    static constexpr size_t IMAGE_OFF = sizeof(ResumeState);
+    static constexpr size_t HIST_OFF = (sizeof(ResumeState) + sizeof(WaveLds<RING_BITS>) + 255u) & ~(size_t)255u;
+    static constexpr size_t BYTES = HIST_OFF + (RING_BITS < 15 ? 32768u : 0u);
 };
 
 // CRC-32 (reflected, poly 0xedb88320) as a polynomial over GF(2): a * b mod P, and the CRC of "A followed by n more
@@ -478,6 +489,12 @@ struct Decoder {
     // A segment's bytes from literals and the near ring are stored at once; bytes whose source is older than
     // the ring ("far") are requested from HBM/L2 and stored only when the next segment starts (complete_pending),
     // so the far-read latency overlaps the decode of the next windows instead of stalling the wave.
+    // Resumable decoders on a small ring (round 4): a call's output goes to THAT call's room, so what is older than the ring
+    // is not in `out`: every flushed byte is written a second time, into the decoder's own 32 KiB history in HBM at
+    // hist[position & 32767], and far reads come from there (L1-bypassing loads: the history is rewritten as the stream goes).
+    static constexpr bool RES_HIST = RES && RING_BITS < 15;
+    static constexpr uint32_t HIST_BYTES = 32768u, HIST_MASK = HIST_BYTES - 1u;
+    uint8_t *hist;
     const uint8_t *far_base;    // far reads: far_base + 32768 is produced-byte `flushed` (or the input, see set_far_base)
     uint64_t far_okmask;        // all ones while far reads may touch the output (128 <= flushed < cap), else 0
     // What a lane with no far source reads (the far load is unconditional: see segment_store): a byte one whole cache
@@ -573,11 +590,16 @@ struct Decoder {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 rv = *(const u32x4 *)(const void *)&L.ring[roff];  // ds_read_b128
             *(u32x4 *)gp = rv;
+            if (RES_HIST) *(u32x4 *)(void *)(hist + ((uint32_t)pos & HIST_MASK)) = rv;
             const uint32_t x0 = rv.x, x1 = rv.y, x2 = rv.z, x3 = rv.w;
 #else
             const uint32_t *rp = (const uint32_t *)(const void *)&L.ring[roff];
             const uint32_t x0 = rp[0], x1 = rp[1], x2 = rp[2], x3 = rp[3];
             gp[0] = x0; gp[1] = x1; gp[2] = x2; gp[3] = x3;
+            if (RES_HIST) {
+                uint32_t *hp = (uint32_t *)(void *)(hist + ((uint32_t)pos & HIST_MASK));
+                hp[0] = x0; hp[1] = x1; hp[2] = x2; hp[3] = x3;
+            }
 #endif
             // Adler32.hs:29-34 advanceNoMod over 16 bytes at once: s = sum d_i, t = sum (16-i) d_i
             const uint32_t s = sum4(x0, sum4(x1, sum4(x2, sum4(x3, 0u))));
@@ -656,6 +678,15 @@ struct Decoder {
                     for (uint32_t k = 0; k < 16u; ++k)  // fixed trip count: no lane-dependent loop exit
                         if (k < valid && pos + k < cap) out[pos + k] = (uint8_t)(xs[k >> 2] >> (8u * (k & 3u)));
                 }
+                if (RES_HIST) {  // ... and into the decoder's history (whole vectors: `pos` is a multiple of 16, zeros past `to` are rewritten by the flush that follows)
+                    uint32_t *hp = (uint32_t *)(void *)(hist + ((uint32_t)pos & HIST_MASK));
+#if PZG_DEVICE_PASS
+                    u32x4 hv = {x0, x1, x2, x3};
+                    *(u32x4 *)hp = hv;
+#else
+                    hp[0] = x0; hp[1] = x1; hp[2] = x2; hp[3] = x3;
+#endif
+                }
                 // Adler32.hs:29-34 advanceNoMod over 16 bytes at once: s = sum d_i, t = sum (16-i) d_i
                 uint32_t s = sum4(x0, sum4(x1, sum4(x2, sum4(x3, 0u))));
                 uint32_t t = dot4(x0, 0x0D0E0F10u, dot4(x1, 0x090A0B0Cu, dot4(x2, 0x05060708u, dot4(x3, 0x01020304u, 0u))));
@@ -699,6 +730,11 @@ struct Decoder {
     PZG_FN void set_far_base()
     {
         if (!HYBRID) return;
+        if (RES_HIST) {  // (a resumable decoder never produces past its room: everything older than the ring is in the history)
+            far_base = hist;
+            far_okmask = ~0ull;
+            return;
+        }
         const bool ok = flushed < cap && flushed >= 128u;  // (below 2 KiB of output nothing is far anyway)
         far_base = ok ? out + (flushed - 32768u) : in - FAR_IDLE;
         far_okmask = ok ? ~0ull : 0ull;
@@ -777,6 +813,14 @@ struct Decoder {
     {
         // lanes that are not far (or a count-only stream whose bytes were never stored) read byte 0 of the output
         uint64_t p = op - back;
+        if (RES_HIST) {
+            const uint32_t hp = is_far ? (uint32_t)p & HIST_MASK : 0u;
+#if PZG_DEVICE_PASS
+            return __builtin_nontemporal_load(hist + hp);
+#else
+            return hist[hp];
+#endif
+        }
         const bool ok = is_far && p < cap;
         p = ok ? p : 0u;
 #if PZG_DEVICE_PASS
@@ -1649,6 +1693,17 @@ struct Decoder {
             ring_store((o < run) & !lane_bit(farm, j), (op32 + o) & RMASK, (uint8_t)PZG_LV(VAL, j), j);
         PZG_LANES_END
         if (HYBRID) {  // sources older than the ring: the stream's own flushed output (fdelta = op - flushed)
+            if (RES_HIST) {  // the decoder's history, by position modulo its size
+                PZG_LANES_BEGIN(j)
+                    const uint32_t hp = lane_bit(farm, j) ? (op32 + (o0 + j) - PZG_LV(DIST, j)) & HIST_MASK : 0u;
+#if PZG_DEVICE_PASS
+                    PZG_LV(pendF, j) = __builtin_nontemporal_load(hist + hp);
+#else
+                    PZG_LV(pendF, j) = hist[hp];
+#endif
+                PZG_LANES_END
+                return;
+            }
             PZG_LANES_BEGIN(j)
                 const uint32_t off = lane_bit(farm, j) ? 32768u + fdelta + (o0 + j) - PZG_LV(DIST, j) : FAR_IDLE;
 #if PZG_DEVICE_PASS
@@ -1711,7 +1766,7 @@ struct Decoder {
             complete_pending();
         }
         PZG_ACCW(8, t_a);
-        if (RES && op + 512u > cap) return ST_OUT_FULL;  // (resumable: never produce past this call's output room)
+        if (RES && op + 512u > cap) return FAST ? EMIT_BAIL : (int)ST_OUT_FULL;  // (resumable: never produce past this call's output room)
         PZG_MARK("e.scan");
         PZG_T0(t_b);
         // bytes of history a distance may reach back over; dist <= 32768, so a clamp is enough (scalar shift + test)
@@ -2239,6 +2294,7 @@ struct Decoder {
     PZG_FN void run(const uint8_t *in_, uint64_t in_len_, uint8_t *out_, uint64_t cap_, StreamResult *res, const uint8_t *dict_ = nullptr,
                     uint32_t dict_len_ = 0)
     {
+        hist = nullptr;
         dict = dict_;
         dict_len = dict_len_;
         in = in_;
@@ -2526,7 +2582,15 @@ struct Decoder {
         for (;;) {
             int st;
             if (deferred == 0u) {
-                const bool checked = qn < QHIGH && fill_queue<false>();
+                // (round 4: the resumable decoder runs the same hot loop as the batch kernel for as long as whole 128-bit
+                // windows lie inside this call's input and nothing special is due; everything else -- the end of the input,
+                // a full room, the reference's chunk accounting across a 64 KiB boundary -- stays with the general code)
+                LaneVec<uint32_t> TK0, TK1;
+                uint64_t S0 = 0, S1 = 0;
+                uint32_t k0 = 0, k1 = 0;
+                const uint32_t why = PZG_RES_HOT_LOOP ? (use_sub ? hot_loop<false, 1>(TK0, TK1, S0, S1, k0, k1) : hot_loop<false, 0>(TK0, TK1, S0, S1, k0, k1))
+                                                      : (uint32_t)HL_GENERAL;
+                const bool checked = why == HL_WINDOW ? window2_rare(TK0, TK1, S0, S1, k0, k1) : (qn < QHIGH && fill_queue<false>());
                 if (!checked) {
                     const int se = emit_segment();
                     if (se == ST_OUT_FULL) {
@@ -2712,9 +2776,11 @@ struct Decoder {
     }
 
     // One call of the resumable decoder on decoder state `rs` (+ its LDS image behind it in HBM).
-    PZG_FN void run_resume(ResumeState *rs, uint32_t *lds_image, const uint8_t *in_, uint64_t in_len_, uint8_t *out_, uint64_t cap_,
+    // hist: the decoder's 32 KiB history in HBM (small-ring instances only; unused, may be null, for the 32 KiB LDS ring)
+    PZG_FN void run_resume(ResumeState *rs, uint32_t *lds_image, uint8_t *hist_, const uint8_t *in_, uint64_t in_len_, uint8_t *out_, uint64_t cap_,
                            uint32_t final_input, StreamResult *res, uint32_t *chunks_out)
     {
+        hist = hist_;
         const uint32_t lane = lane_id();
         in = in_;
         in_len = in_len_;
@@ -2752,6 +2818,7 @@ struct Decoder {
         const uint64_t flushed0 = flushed;
         out = out_ - flushed0;  // this call's room starts at produced-byte `flushed0`
         cap = flushed0 + cap_;
+        set_far_base();
         PZG_LANES_BEGIN(j)
             PZG_LV(QT, j) = rs->QT[j];
         PZG_LANES_END

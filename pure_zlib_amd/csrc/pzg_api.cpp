@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -51,36 +52,96 @@ constexpr int LANES_PER_SHARD = 4;
 constexpr int COUNTER_SLOTS = 16;           // device-pointer launches in flight on one shard, each with its own counter
 constexpr size_t RANGE_MAX_OUT = 256ull << 20;  // a range's packed output stays below this (bounds the pinned staging)
 
-// a small pool of helper threads for the host-side packing / copy-out of the host-pointer path
+// A pool of helper threads for the host-side packing / copy-out of the host-pointer paths.  The threads are started on first
+// use and live as long as the context (round 4: creating two dozen threads per range cost more than the copying they did);
+// run() may be called from several threads at once -- every job is a list of parts that the workers AND the caller take one
+// at a time, so a job always completes even if no worker could be started.
 class Helpers {
 public:
     explicit Helpers(unsigned n) : n_(n ? n : 1u) {}
+    ~Helpers()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
     unsigned size() const { return n_; }
-    // f(part, parts): runs on `parts` threads (the caller is one of them) and returns when all are done
+    // f(part, parts): every part in 0 .. parts - 1 runs exactly once, on some thread; returns when all are done
     template <class F>
-    void run(unsigned parts, F &&f) const
+    void run(unsigned parts, F &&f)
     {
         if (parts <= 1) {
             f(0u, 1u);
             return;
         }
-        std::vector<std::thread> th;
-        th.reserve(parts - 1);
-        unsigned started = 1;
-        for (; started < parts; ++started) {
-            try {
-                th.emplace_back([&f, started, parts] { f(started, parts); });
-            } catch (...) {  // no more threads to be had: the caller does the remaining parts itself
-                break;
-            }
+        auto job = std::make_shared<Job>();
+        job->parts = parts;
+        job->fn = [&f, parts](unsigned p) { f(p, parts); };
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            start_workers();
+            jobs_.push_back(job);
         }
-        f(0u, parts);
-        for (unsigned t = started; t < parts; ++t) f(t, parts);
-        for (auto &x : th) x.join();
+        cv_.notify_all();
+        work_on(*job);
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [&] { return job->done == job->parts; });
     }
 
 private:
+    struct Job {
+        std::function<void(unsigned)> fn;
+        unsigned parts = 0;
+        std::atomic<unsigned> next{0};
+        unsigned done = 0;  // (under mu_)
+    };
+    void work_on(Job &j)
+    {
+        for (;;) {
+            const unsigned p = j.next.fetch_add(1u);
+            if (p >= j.parts) return;
+            j.fn(p);
+            bool last;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                last = ++j.done == j.parts;
+            }
+            if (last) done_cv_.notify_all();
+        }
+    }
+    void start_workers()  // (mu_ held)
+    {
+        while (workers_.size() + 1 < n_) {
+            try {
+                workers_.emplace_back([this] {
+                    std::unique_lock<std::mutex> g(mu_);
+                    for (;;) {
+                        cv_.wait(g, [&] { return quit_ || !jobs_.empty(); });
+                        if (quit_) return;
+                        std::shared_ptr<Job> j = jobs_.front();
+                        if (j->next.load() >= j->parts) {  // every part is taken: the job leaves the queue
+                            jobs_.pop_front();
+                            continue;
+                        }
+                        g.unlock();
+                        work_on(*j);
+                        g.lock();
+                    }
+                });
+            } catch (...) {  // no more threads to be had: the callers do what the missing workers would have done
+                break;
+            }
+        }
+    }
     unsigned n_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<std::shared_ptr<Job>> jobs_;
+    std::vector<std::thread> workers_;
+    bool quit_ = false;
 };
 
 constexpr int NSLOT = 3;  // ranges in flight per lane: one being packed / uploaded, one decoding, one downloading / copied out
@@ -1148,11 +1209,36 @@ struct pzg_decoder {
     size_t stride = 0;
     uint8_t *d_state = nullptr;  // n x stride: ResumeState + LDS image per decoder
     uint32_t *d_counter = nullptr;
-    Arena d_in, d_out, d_meta;
-    Pinned h_in, h_out, h_meta;  // page-locked staging (grow-only): the copies run at link speed and really are asynchronous
+    Arena d_in, d_out, d_meta, d_dense, d_doff;
+    Pinned h_in, h_out, h_meta, h_doff;  // page-locked staging (grow-only): the copies run at link speed and really are asynchronous
     hipStream_t stream = nullptr;
+    // a large feed is cut into ranges of decoders that overlap their uploads, launches, downloads and host copies
+    static constexpr int MAXR = 8;
+    hipStream_t s_up = nullptr, s_res = nullptr, s_dat = nullptr;
+    hipStream_t s_kr[MAXR] = {};  // a launch stream per range: a range's decoders fill a sixth of the chip, the ranges' kernels run side by side
+    hipEvent_t ev_up[MAXR] = {}, ev_k[MAXR] = {}, ev_res[MAXR] = {}, ev_dat[MAXR] = {};
+    bool pipe_ready = false;
     std::mutex mu;
 };
+
+namespace {
+int decoder_pipe_prepare(pzg_ctx *ctx, pzg_decoder *d)
+{
+    if (d->pipe_ready) return PZG_RC_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&d->s_up, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&d->s_res, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&d->s_dat, hipStreamNonBlocking));
+    for (int c = 0; c < pzg_decoder::MAXR; ++c) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&d->s_kr[c], hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&d->ev_up[c], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&d->ev_k[c], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&d->ev_res[c], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&d->ev_dat[c], hipEventDisableTiming));
+    }
+    d->pipe_ready = true;
+    return PZG_RC_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -1197,12 +1283,22 @@ void pzg_decoder_destroy(pzg_decoder *dec)
 {
     if (!dec) return;
     (void)hipSetDevice(dec->device);
-    if (dec->stream) (void)hipStreamSynchronize(dec->stream);
-    for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta})
+    for (hipStream_t st : {dec->stream, dec->s_up, dec->s_res, dec->s_dat})
+        if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : dec->s_kr)
+        if (st) (void)hipStreamSynchronize(st);
+    for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta, &dec->d_dense, &dec->d_doff})
         if (a->p) (void)hipFree(a->p);
-    for (Pinned *h : {&dec->h_in, &dec->h_out, &dec->h_meta}) pinned_release(*h);
+    for (Pinned *h : {&dec->h_in, &dec->h_out, &dec->h_meta, &dec->h_doff}) pinned_release(*h);
     if (dec->d_state) (void)hipFree(dec->d_state);
     if (dec->d_counter) (void)hipFree(dec->d_counter);
+    for (int c = 0; c < pzg_decoder::MAXR; ++c)
+        for (hipEvent_t e : {dec->ev_up[c], dec->ev_k[c], dec->ev_res[c], dec->ev_dat[c]})
+            if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {dec->s_up, dec->s_res, dec->s_dat})
+        if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : dec->s_kr)
+        if (st) (void)hipStreamDestroy(st);
     if (dec->stream) (void)hipStreamDestroy(dec->stream);
     pzg_ctx *ctx = dec->ctx;
     delete dec;
@@ -1277,20 +1373,8 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
         if ((rc = arena_reserve(ctx, dec->d_in, ip + 64)) != PZG_RC_OK) return rc;
         if ((rc = arena_reserve(ctx, dec->d_out, op + 64)) != PZG_RC_OK) return rc;
         if ((rc = arena_reserve(ctx, dec->d_meta, meta_bytes)) != PZG_RC_OK) return rc;
-        // the decoders' inputs, packed by the context's helper threads (a batch of thousands of decoders moves 100+ MiB)
-        const unsigned parts = ip >= (8u << 20) ? ctx->helpers->size() : 1u;
-        uint8_t *hin = dec->h_in.p;
-        ctx->helpers->run(parts, [&](unsigned part, unsigned nparts) {
-            for (uint32_t j = (uint32_t)((uint64_t)m * part / nparts), e = (uint32_t)((uint64_t)m * (part + 1) / nparts); j < e; ++j)
-                if (ilen[j]) memcpy(hin + ioff[j], in_base + in_off[j], ilen[j]);
-        });
-        uint8_t *dm = (uint8_t *)dec->d_meta.p;
-        hipStream_t st = dec->stream;
-        HIP_TRY(ctx, hipMemcpyAsync(dm, dec->h_meta.p, 32 * (size_t)m, hipMemcpyHostToDevice, st));
-        uint8_t *d_final = dm + 68 * (size_t)m;
-        HIP_TRY(ctx, hipMemcpyAsync(d_final, h_final, m, hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(dec->d_in.p, hin, ip, hipMemcpyHostToDevice, st));
         pzg::ResumeArgs a{};
+        uint8_t *dm = (uint8_t *)dec->d_meta.p;
         a.state_stride = dec->stride;
         a.in_base = (const uint8_t *)dec->d_in.p;
         a.out_base = (uint8_t *)dec->d_out.p;
@@ -1304,33 +1388,284 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
         a.adler = (uint32_t *)(a.status + m);
         a.chunks = a.adler + m;
         a.detail = a.chunks + m;
-        a.final_in = d_final;
+        a.final_in = dm + 68 * (size_t)m;
         a.counter = dec->d_counter;
-        // the decoders of this call: one launch when they are all of them (or one contiguous run), else one launch per run
-        uint32_t j0 = 0;
-        while (j0 < m) {
-            uint32_t j1 = j0 + 1;
-            const uint32_t first = idx ? idx[j0] : 0u;
-            if (!idx) j1 = m;
-            else
-                while (j1 < m && idx[j1] == first + (j1 - j0)) ++j1;
-            pzg::ResumeArgs r = a;
-            r.state_base = dec->d_state + dec->stride * (size_t)first;
-            r.in_off += j0;
-            r.in_len += j0;
-            r.out_off += j0;
-            r.out_cap += j0;
-            r.out_len += j0;
-            r.in_used += j0;
-            r.status += j0;
-            r.adler += j0;
-            r.chunks += j0;
-            r.detail += 2 * (size_t)j0;
-            r.final_in += j0;
-            r.n = j1 - j0;
-            HIP_TRY(ctx, pzg::launch_resume(r, num_cus, st));
-            j0 = j1;
+        // one launch per run of consecutive decoder numbers among positions [j0, j1) of the call
+        uint64_t *dense_host = nullptr;  // (set by the pipelined path when the kernels write their results into host memory)
+        auto launch_runs = [&](uint32_t j0, uint32_t jend, uint32_t *counter, hipStream_t st, uint64_t dense_region = 0, uint32_t *dense_cursor = nullptr) -> hipError_t {
+            if (dense_cursor) {
+                const hipError_t e = hipMemsetAsync(dense_cursor, 0, sizeof(uint32_t), st);
+                if (e != hipSuccess) return e;
+            }
+            while (j0 < jend) {
+                uint32_t j1 = j0 + 1;
+                const uint32_t first = idx ? idx[j0] : j0;
+                if (!idx) j1 = jend;
+                else
+                    while (j1 < jend && idx[j1] == first + (j1 - j0)) ++j1;
+                pzg::ResumeArgs r = a;
+                r.state_base = dec->d_state + dec->stride * (size_t)first;
+                r.in_off += j0;
+                r.in_len += j0;
+                r.out_off += j0;
+                r.out_cap += j0;
+                r.out_len += j0;
+                r.in_used += j0;
+                r.status += j0;
+                r.adler += j0;
+                r.chunks += j0;
+                r.detail += 2 * (size_t)j0;
+                r.final_in += j0;
+                r.n = j1 - j0;
+                r.counter = counter;
+                if (dense_cursor) {
+                    r.dense = (uint8_t *)dec->d_dense.p;
+                    r.dense_region = dense_region;
+                    r.dense_cursor = dense_cursor;
+                    r.dense_off = (dense_host ? dense_host : (uint64_t *)dec->d_doff.p) + j0;
+                }
+                const hipError_t e = pzg::launch_resume(r, num_cus, st);
+                if (e != hipSuccess) return e;
+                j0 = j1;
+            }
+            return hipSuccess;
+        };
+        // ---- a large feed: ranges of decoders flow through upload -> launch -> results -> download -> copy-out, the stages
+        // of neighbouring ranges overlapping (round 4: with the small-ring kernel the launches no longer dominate a feed)
+        if (m >= 512u && ip + op >= (64ull << 20)) {
+            if ((rc = decoder_pipe_prepare(ctx, dec)) != PZG_RC_OK) return rc;
+            // (what the decoders deliver is packed back to back on the device and comes down in one linear copy per range)
+            if ((rc = arena_reserve(ctx, dec->d_dense, op + 64)) != PZG_RC_OK) return rc;
+            if ((rc = arena_reserve(ctx, dec->d_doff, 8 * (size_t)m + 64)) != PZG_RC_OK) return rc;
+            if ((rc = pinned_reserve(ctx, dec->h_doff, 8 * (size_t)m + 64)) != PZG_RC_OK) return rc;
+            uint64_t *doff = (uint64_t *)dec->h_doff.p;  // where decoder j's bytes start in the packed buffers (device and host alike)
+            constexpr uint32_t R = 8;
+            static_assert(R <= (uint32_t)pzg_decoder::MAXR, "an event set per range");
+            // (what does not overlap is the first range's upload + decode and the last range's copy-out: the ranges shrink towards the end)
+            static const uint32_t WEIGHT[R] = {10, 10, 9, 8, 7, 6, 5, 4};
+            uint32_t lo[R + 1];
+            {
+                uint32_t wsum = 0, wacc[R];
+                for (uint32_t c = 0; c < R; ++c) wacc[c] = (wsum += WEIGHT[c]);
+                const size_t tot = ip + op;
+                size_t acc = 0;
+                uint32_t c = 0;
+                lo[0] = 0;
+                for (uint32_t j = 0; j < m; ++j) {
+                    acc += pad16(in_len[j]) + 16 + pad16(out_cap[j]);
+                    while (c + 1 < R && acc >= tot / wsum * wacc[c]) lo[++c] = j + 1;
+                }
+                while (c < R) lo[++c] = m;
+            }
+            uint8_t *hin = dec->h_in.p, *hout = dec->h_out.p;
+            uint8_t *res = dec->h_meta.p + 32 * (size_t)m;
+            uint64_t *olen = (uint64_t *)res, *used = olen + m;
+            int32_t *stt = (int32_t *)(used + m);
+            uint32_t *ad = (uint32_t *)(stt + m), *ch = ad + m, *det = ch + m;
+            // The results (44 bytes per decoder) are written by the kernels STRAIGHT into the page-locked meta block -- it is mapped
+            // into the device's address space -- so that they are there when a range's kernel ends: as copies they queued up
+            // behind the megabytes of the ranges in front on the one download engine.  (Pageable fallback staging: copies.)
+            const bool direct = !dec->h_meta.pageable && !dec->h_doff.pageable;
+            if (direct) {
+                dense_host = doff;
+                a.out_len = olen;
+                a.in_used = used;
+                a.status = stt;
+                a.adler = ad;
+                a.chunks = ch;
+                a.detail = det;
+            }
+            hipError_t herr = hipSuccess;
+            const char *hwhat = "";
+#define FEED_TRY(call)                              \
+    do {                                            \
+        if (herr == hipSuccess) {                   \
+            herr = (call);                          \
+            if (herr != hipSuccess) hwhat = #call;  \
+        }                                           \
+    } while (0)
+            FEED_TRY(hipMemcpyAsync(dm, dec->h_meta.p, 32 * (size_t)m, hipMemcpyHostToDevice, dec->s_up));
+            FEED_TRY(hipMemcpyAsync(dm + 68 * (size_t)m, h_final, m, hipMemcpyHostToDevice, dec->s_up));
+            std::mutex pm;
+            std::condition_variable pcv;
+            uint32_t issued = 0, fetched = 0;
+            bool stop = false, stop_copy = false;
+            hipError_t derr = hipSuccess;
+#if defined(PZG_LAB)
+            const bool trace = getenv("PZG_TRACE_HOST") != nullptr;
+            const auto t_feed0 = std::chrono::steady_clock::now();
+            auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+            double t_pack = 0, t_res = 0, t_dat = 0, t_out = 0;
+#endif
+            // the third thread: hands a fetched range to the caller (results into the caller's arrays, bytes out of the staging)
+            std::thread copier([&] {
+                for (uint32_t c = 0; c < R; ++c) {
+                    {
+                        std::unique_lock<std::mutex> g(pm);
+                        pcv.wait(g, [&] { return fetched > c || stop_copy; });
+                        if (fetched <= c) return;
+                    }
+                    const uint32_t j0 = lo[c], j1 = lo[c + 1];
+                    if (j0 == j1) continue;
+#if defined(PZG_LAB)
+                    const auto t0 = std::chrono::steady_clock::now();
+#endif
+                    uint64_t delivered = 0;
+                    for (uint32_t j = j0; j < j1; ++j) {
+                        out_len[j] = olen[j];
+                        state[j] = stt[j];
+                        in_used[j] = used[j];
+                        chunks[j] = ch[j];
+                        if (adler) adler[j] = ad[j];
+                        if (detail) {
+                            detail[2 * (size_t)j] = det[2 * (size_t)j];
+                            detail[2 * (size_t)j + 1] = det[2 * (size_t)j + 1];
+                        }
+                        delivered += olen[j] <= ocap[j] ? olen[j] : ocap[j];
+                    }
+                    const uint32_t nn = j1 - j0;
+                    ctx->helpers->run(delivered >= (4u << 20) ? (ctx->helpers->size() + 1u) / 2u : 1u, [&](unsigned part, unsigned nparts) {
+                        for (uint32_t j = j0 + (uint32_t)((uint64_t)nn * part / nparts), e2 = j0 + (uint32_t)((uint64_t)nn * (part + 1) / nparts); j < e2; ++j)
+                            if (olen[j]) memcpy(out_base + out_off[j], hout + doff[j], olen[j] <= ocap[j] ? olen[j] : ocap[j]);
+                    });
+#if defined(PZG_LAB)
+                    t_out += ms_since(t0);
+#endif
+                }
+            });
+            // the second thread: waits for a range's results and fetches what its decoders delivered
+            std::thread drainer([&] {
+                (void)hipSetDevice(dec->device);
+                for (uint32_t c = 0; c < R; ++c) {
+                    {
+                        std::unique_lock<std::mutex> g(pm);
+                        pcv.wait(g, [&] { return issued > c || stop; });
+                        if (issued <= c) return;
+                    }
+                    const uint32_t j0 = lo[c], j1 = lo[c + 1];
+                    if (j0 == j1) {
+                        {
+                            std::lock_guard<std::mutex> g(pm);
+                            fetched = c + 1;
+                        }
+                        pcv.notify_all();
+                        continue;
+                    }
+#if defined(PZG_LAB)
+                    auto t0 = std::chrono::steady_clock::now();
+#endif
+                    hipError_t e = hipEventSynchronize(dec->ev_res[c]);
+#if defined(PZG_LAB)
+                    t_res += ms_since(t0);
+                    t0 = std::chrono::steady_clock::now();
+#endif
+                    uint64_t delivered = 0;  // the decoders of the range packed their bytes behind one another from ooff[j0] on (whole 16-byte vectors each)
+                    for (uint32_t j = j0; j < j1 && e == hipSuccess; ++j) delivered += pad16(olen[j]);
+                    if (e == hipSuccess && delivered != 0) {
+                        e = hipMemcpyAsync(hout + ooff[j0], (const uint8_t *)dec->d_dense.p + ooff[j0], delivered, hipMemcpyDeviceToHost, dec->s_dat);
+                        if (e == hipSuccess) e = hipStreamSynchronize(dec->s_dat);
+                    }
+#if defined(PZG_LAB)
+                    t_dat += ms_since(t0);
+#endif
+                    {
+                        std::lock_guard<std::mutex> g(pm);
+                        if (e != hipSuccess && derr == hipSuccess) derr = e;
+                        if (e == hipSuccess) fetched = c + 1;
+                        else stop_copy = true;
+                    }
+                    pcv.notify_all();
+                    if (e != hipSuccess) return;
+                }
+            });
+            for (uint32_t c = 0; c < R && herr == hipSuccess; ++c) {
+                const uint32_t j0 = lo[c], j1 = lo[c + 1];
+                if (j0 != j1) {
+                    const uint32_t nn = j1 - j0;
+                    const size_t ib = (j1 < m ? ioff[j1] : ip) - ioff[j0];
+#if defined(PZG_LAB)
+                    const auto tp0 = std::chrono::steady_clock::now();
+#endif
+                    ctx->helpers->run(ib >= (4u << 20) ? ctx->helpers->size() : 1u, [&](unsigned part, unsigned nparts) {
+                        for (uint32_t j = j0 + (uint32_t)((uint64_t)nn * part / nparts), e2 = j0 + (uint32_t)((uint64_t)nn * (part + 1) / nparts); j < e2; ++j)
+                            if (ilen[j]) memcpy(hin + ioff[j], in_base + in_off[j], ilen[j]);
+                    });
+#if defined(PZG_LAB)
+                    t_pack += ms_since(tp0);
+#endif
+                    if (ib) FEED_TRY(hipMemcpyAsync((uint8_t *)dec->d_in.p + ioff[j0], hin + ioff[j0], ib, hipMemcpyHostToDevice, dec->s_up));
+                    FEED_TRY(hipEventRecord(dec->ev_up[c], dec->s_up));
+                    hipStream_t s_k = dec->s_kr[c];
+                    FEED_TRY(hipStreamWaitEvent(s_k, dec->ev_up[c], 0));
+                    // (a counter word, a packing cursor and a stream of its own per range: the launches overlap; the range's packed region
+                    // starts where its rooms start)
+                    FEED_TRY(launch_runs(j0, j1, dec->d_counter + 8u * c, s_k, ooff[j0], dec->d_counter + 8u * c + 1u));
+                    FEED_TRY(hipEventRecord(dec->ev_k[c], s_k));
+                    if (direct) {
+                        FEED_TRY(hipEventRecord(dec->ev_res[c], s_k));
+                    } else {
+                    FEED_TRY(hipStreamWaitEvent(dec->s_res, dec->ev_k[c], 0));
+                    // the range's results: six short arrays (36 bytes per decoder)
+                    FEED_TRY(hipMemcpyAsync(olen + j0, a.out_len + j0, 8 * (size_t)nn, hipMemcpyDeviceToHost, dec->s_res));
+                    FEED_TRY(hipMemcpyAsync(used + j0, a.in_used + j0, 8 * (size_t)nn, hipMemcpyDeviceToHost, dec->s_res));
+                    FEED_TRY(hipMemcpyAsync(stt + j0, a.status + j0, 4 * (size_t)nn, hipMemcpyDeviceToHost, dec->s_res));
+                    FEED_TRY(hipMemcpyAsync(ad + j0, a.adler + j0, 4 * (size_t)nn, hipMemcpyDeviceToHost, dec->s_res));
+                    FEED_TRY(hipMemcpyAsync(ch + j0, a.chunks + j0, 4 * (size_t)nn, hipMemcpyDeviceToHost, dec->s_res));
+                    FEED_TRY(hipMemcpyAsync(det + 2 * (size_t)j0, a.detail + 2 * (size_t)j0, 8 * (size_t)nn, hipMemcpyDeviceToHost, dec->s_res));
+                    FEED_TRY(hipMemcpyAsync(doff + j0, (const uint64_t *)dec->d_doff.p + j0, 8 * (size_t)nn, hipMemcpyDeviceToHost, dec->s_res));
+                    FEED_TRY(hipEventRecord(dec->ev_res[c], dec->s_res));
+                    }
+                }
+                if (herr == hipSuccess) {
+                    {
+                        std::lock_guard<std::mutex> g(pm);
+                        issued = c + 1;
+                    }
+                    pcv.notify_all();
+                }
+            }
+#undef FEED_TRY
+            {
+                std::lock_guard<std::mutex> g(pm);
+                stop = true;
+            }
+            pcv.notify_all();
+            drainer.join();
+            {
+                std::lock_guard<std::mutex> g(pm);
+                stop_copy = true;  // (a no-op when every range was fetched: the copier finishes them all first)
+            }
+            pcv.notify_all();
+            copier.join();
+#if defined(PZG_LAB)
+            if (trace)
+                fprintf(stderr, "[pzg] feed: %u decoders, %.1f MiB in, %.1f MiB of rooms: %.1f ms (issuing thread: packing %.1f; draining thread: waiting for "
+                        "results %.1f, fetching data %.1f, copy-out %.1f)\n", m, ip / 1048576.0, op / 1048576.0, ms_since(t_feed0), t_pack, t_res, t_dat, t_out);
+#endif
+            if (herr == hipSuccess && derr != hipSuccess) {
+                herr = derr;
+                hwhat = "download of a range";
+            }
+            if (herr != hipSuccess) {
+                for (hipStream_t st : {dec->s_up, dec->s_res, dec->s_dat}) (void)hipStreamSynchronize(st);
+                for (hipStream_t st : dec->s_kr) (void)hipStreamSynchronize(st);
+                return hip_fail(ctx, herr, hwhat);
+            }
+            return PZG_RC_OK;
         }
+        // ---- a small feed: one stream, one range
+        // the decoders' inputs, packed by the context's helper threads (a batch of thousands of decoders moves 100+ MiB)
+        const unsigned parts = ip >= (8u << 20) ? ctx->helpers->size() : 1u;
+        uint8_t *hin = dec->h_in.p;
+        ctx->helpers->run(parts, [&](unsigned part, unsigned nparts) {
+            for (uint32_t j = (uint32_t)((uint64_t)m * part / nparts), e = (uint32_t)((uint64_t)m * (part + 1) / nparts); j < e; ++j)
+                if (ilen[j]) memcpy(hin + ioff[j], in_base + in_off[j], ilen[j]);
+        });
+        hipStream_t st = dec->stream;
+        HIP_TRY(ctx, hipMemcpyAsync(dm, dec->h_meta.p, 32 * (size_t)m, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dm + 68 * (size_t)m, h_final, m, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dec->d_in.p, hin, ip, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, launch_runs(0, m, dec->d_counter, st));
         // results first (36 bytes per decoder), then only what the decoders delivered: a decoder's room is out_cap, what it
         // fills of it is usually far less -- one copy over the whole room when most of it is used, else one per decoder run
         uint8_t *res = dec->h_meta.p + 32 * (size_t)m;

@@ -48,6 +48,12 @@ struct ResumeArgs {
     uint32_t *chunks;         // n: 32 KiB chunks the reference would have published so far (cumulative)
     uint32_t *counter;
     uint32_t n;
+    // optional (null: off): every decoder also packs what it delivered behind the others' -- dense + dense_region + 16 * (the value
+    // of *dense_cursor it drew), reported in dense_off[i] -- so that the host fetches one linear span instead of mostly empty rooms
+    uint8_t *dense;
+    uint64_t dense_region;
+    uint32_t *dense_cursor;  // zeroed by the launcher's caller; counts 16-byte units
+    uint64_t *dense_off;     // n
 };
 hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream);
 size_t resume_state_bytes();   // one decoder's slot: ResumeState + LDS image

@@ -61,6 +61,32 @@ static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t c
     free(lds);
 }
 
+// the resumable instance (decompressIncremental): one call on a decoder whose slot (ResumeState + LDS image + for the small
+// rings its 32 KiB history) the caller keeps in `state` (pzm_resume_state_bytes_rb(ring) bytes, zeroed for a fresh decoder)
+template <int RB>
+static int resume_feed(uint8_t *state, const uint8_t *in, uint64_t in_len, uint32_t final_input, uint8_t *out, uint64_t cap, pzm_result *r,
+                       uint32_t *chunks)
+{
+    auto *lds = (pzg::WaveLds<RB> *)aligned_alloc(16, (sizeof(pzg::WaveLds<RB>) + 15u) & ~(size_t)15u);
+    memset(lds, 0xA5, sizeof(*lds));
+    uint8_t *buf = (uint8_t *)malloc(in_len + 16);
+    memset(buf, 0xEE, in_len + 16);
+    if (in_len) memcpy(buf + 8, in, in_len);
+    pzg::Decoder<RB, false, true> dec(*lds);
+    pzg::StreamResult sr;
+    dec.run_resume((pzg::ResumeState *)state, (uint32_t *)(state + pzg::ResumeSlot<RB>::IMAGE_OFF), state + pzg::ResumeSlot<RB>::HIST_OFF, buf + 8,
+                   in_len, out, cap, final_input, &sr, chunks);
+    r->status = sr.status;
+    r->detail0 = sr.detail0;
+    r->detail1 = sr.detail1;
+    r->adler = sr.adler;
+    r->out_len = sr.out_len;
+    r->in_used = sr.in_used;
+    free(buf);
+    free(lds);
+    return 0;
+}
+
 extern "C" {
 
 int pzm_decompress(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, int ring_bits, pzm_result *r)
@@ -87,31 +113,24 @@ int pzm_decompress_gzip(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64
     return 0;
 }
 
-// the resumable instance (decompressIncremental): one call on a decoder whose state (ResumeState + LDS image) the
-// caller keeps in `state` (pzm_resume_state_bytes() bytes, zeroed for a fresh decoder)
-uint32_t pzm_resume_state_bytes(void) { return (uint32_t)(sizeof(pzg::ResumeState) + sizeof(pzg::WaveLds<15>)); }
+uint32_t pzm_resume_state_bytes_rb(int rb)
+{
+    return (uint32_t)(rb == 15 ? pzg::ResumeSlot<15>::BYTES : rb == 12 ? pzg::ResumeSlot<12>::BYTES : pzg::ResumeSlot<11>::BYTES);
+}
+uint32_t pzm_resume_state_bytes(void) { return pzm_resume_state_bytes_rb(15); }
 
+int pzm_resume_feed_rb(int rb, uint8_t *state, const uint8_t *in, uint64_t in_len, uint32_t final_input, uint8_t *out, uint64_t cap, pzm_result *r,
+                       uint32_t *chunks)
+{
+    if (rb == 15) return resume_feed<15>(state, in, in_len, final_input, out, cap, r, chunks);
+    if (rb == 12) return resume_feed<12>(state, in, in_len, final_input, out, cap, r, chunks);
+    if (rb == 11) return resume_feed<11>(state, in, in_len, final_input, out, cap, r, chunks);
+    return -1;
+}
 int pzm_resume_feed(uint8_t *state, const uint8_t *in, uint64_t in_len, uint32_t final_input, uint8_t *out, uint64_t cap, pzm_result *r,
                     uint32_t *chunks)
 {
-    auto *lds = (pzg::WaveLds<15> *)aligned_alloc(16, sizeof(pzg::WaveLds<15>));
-    memset(lds, 0xA5, sizeof(*lds));
-    uint8_t *buf = (uint8_t *)malloc(in_len + 16);
-    memset(buf, 0xEE, in_len + 16);
-    if (in_len) memcpy(buf + 8, in, in_len);
-    pzg::Decoder<15, false, true> dec(*lds);
-    pzg::StreamResult sr;
-    dec.run_resume((pzg::ResumeState *)state, (uint32_t *)(state + sizeof(pzg::ResumeState)), buf + 8, in_len, out, cap, final_input, &sr,
-                   chunks);
-    r->status = sr.status;
-    r->detail0 = sr.detail0;
-    r->detail1 = sr.detail1;
-    r->adler = sr.adler;
-    r->out_len = sr.out_len;
-    r->in_used = sr.in_used;
-    free(buf);
-    free(lds);
-    return 0;
+    return pzm_resume_feed_rb(15, state, in, in_len, final_input, out, cap, r, chunks);
 }
 
 // with a preset dictionary (PZG_FDICT extension): the 32 KiB-ring instance

@@ -158,9 +158,9 @@ class ModelDecoder:
     """Drives pzm_resume_feed the way the host mirror drives pzg_decoder_feed: the unconsumed tail goes in front of the next
     piece, a call that ran out of room is repeated, 32 KiB chunks are published as the device-side count says."""
 
-    def __init__(self, M, room):
-        self.M, self.room = M, room
-        self.state = C.create_string_buffer(M.pzm_resume_state_bytes())
+    def __init__(self, M, room, rb=15):
+        self.M, self.room, self.rb = M, room, rb
+        self.state = C.create_string_buffer(M.pzm_resume_state_bytes_rb(rb))
         self.tail, self.pending, self.published, self.total = b"", bytearray(), 0, bytearray()
         self.events = [("NeedMore",)]
 
@@ -172,7 +172,7 @@ class ModelDecoder:
         while True:
             out = C.create_string_buffer(self.room)
             r, ch = R(), C.c_uint32(0)
-            self.M.pzm_resume_feed(self.state, data, len(data), 0, out, self.room, C.byref(r), C.byref(ch))
+            assert self.M.pzm_resume_feed_rb(self.rb, self.state, data, len(data), 0, out, self.room, C.byref(r), C.byref(ch)) == 0
             self.pending += out.raw[:r.out_len]
             self.total += out.raw[:r.out_len]
             while self.published < ch.value:
@@ -198,13 +198,17 @@ class ModelDecoder:
 def model_lib(model):
     flags = os.environ.get("PZG_MODEL_FLAGS", "").split()
     M = C.CDLL(os.path.join(ROOT, "tests", "model", "libpzgmodel%s.so" % ("_" + hashlib.md5(" ".join(flags).encode()).hexdigest()[:8] if flags else "")))
-    M.pzm_resume_state_bytes.restype = C.c_uint32
-    M.pzm_resume_feed.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(R), C.POINTER(C.c_uint32)]
+    M.pzm_resume_state_bytes_rb.restype = C.c_uint32
+    M.pzm_resume_state_bytes_rb.argtypes = [C.c_int]
+    M.pzm_resume_feed_rb.argtypes = [C.c_int, C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(R), C.POINTER(C.c_uint32)]
     M.pzm_decompress_dict.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(R)]
     return M
 
 
-def test_model_incremental_event_trace(model_lib, oracle):
+# (the resumable kernel is built for ring 12 -- PZG_RES_RING: a small LDS ring + the decoder's 32 KiB history in HBM; the
+# 32 KiB LDS ring and ring 11 are the same template and stay tested)
+@pytest.mark.parametrize("rb", [12, 15, 11])
+def test_model_incremental_event_trace(model_lib, oracle, rb):
     """The ZlibDecoder protocol (Monad.hs:163-197, OutputWindow.hs:45-54): NeedMore / Chunk(32768) / Chunk(rest) / Done /
     DecompError in exactly the reference's order, for the nine fixtures and seeded streams, fed 7000 bytes, 1 byte, 100
     bytes at a time, with empty pieces, corrupted streams and output rooms from 4 KiB up."""
@@ -225,7 +229,7 @@ def test_model_incremental_event_trace(model_lib, oracle):
         if k % 13 == 0:
             pieces.insert(len(pieces) // 2, b"")
         eo, ro, oo = oracle.trace(pieces)
-        dec = ModelDecoder(model_lib, room)
+        dec = ModelDecoder(model_lib, room, rb)
         for p in pieces:
             if not dec.feed(p):
                 break
@@ -252,7 +256,7 @@ def test_model_incremental_bad_header_with_fdict_bit(model_lib, oracle):
         for step in (1, 2, 5):
             pieces = [z[i:i + step] for i in range(0, len(z), step)]
             eo, _ro, _oo = oracle.trace(pieces)
-            dec = ModelDecoder(model_lib, 4096)
+            dec = ModelDecoder(model_lib, 4096, 12)
             for p in pieces:
                 if not dec.feed(p):
                     break
