@@ -442,8 +442,9 @@ def main():
         inc_plain = [corpus.zipf_text(256 * 1024, 7000 + k) for k in range(32)]
         inc_z = [zlib.compress(t, 6) for t in inc_plain]
         result["incremental_variant"] = HB.incremental_throughput(ctx, inc_z, inc_plain, n_decoders=args.incremental_decoders)
-        result["incremental_variant"]["note"] = ("pzg_decoder_feed: resumable decoders on the device (32 KiB LDS ring instance, 4 per CU), "
-                                                 "256 KiB level-6 text streams; time = the feed calls only (pack + H2D + launch + D2H + copy-out)")
+        result["incremental_variant"]["note"] = ("pzg_decoder_feed: resumable decoders on the device (4 KiB LDS ring + a 32 KiB history per decoder in "
+                                                 "HBM, 16 decoders per CU; a feed is pipelined in 8 ranges), 256 KiB level-6 text streams; time = the feed "
+                                                 "calls only (pack + H2D + launch + D2H + copy-out)")
 
     # ---- CPU baseline, rank 0 at N=1 only: the oracle ("port": the bit-at-a-time restatement of pure-zlib) and system
     # zlib, on this box's host cores.  All cores: the WHOLE timed batch.  One thread: a bounded sample of it (the whole
