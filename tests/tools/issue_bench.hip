@@ -77,15 +77,16 @@ enum Pat {
     P_SOR_CND_MIX,
     P_SOR_CND64_MIX,
     P_VCMP_CND_FAR,
+    P_DECODER_MIX,
     P_COUNT
 };
 static const char *pat_name[P_COUNT] = {"valu_e32(4B,indep)", "valu_vop3 alignbit(8B)", "valu_sdwa", "valu_dpp row_shr", "v_readlane->s",
                                         "v_cndmask sgpr-mask", "v_cmp->sgpr", "salu s_add(indep)", "s_bitset1_b64", "s_cmp+cbranch(not taken)",
                                         "s_branch(taken,next)", "walk step x4 (nt)", "mix 1 valu+1 salu", "ds_bpermute", "ds_read_b32",
                                         "ds_write_b8", "s_nop 0", "s_waitcnt lgkm(0)", "valu_e32 dependent", "salu dependent", "mix 2 valu+1 salu",
-                                        "walk step, exit taken/8", "vop2 e32 + literal(8B)", "vop1 v_mov e32", "v_mbcnt_lo (vop3)", "v_add_u32_e64 (vop3,2op)", "v_lshl_add_u32", "v_cmp e32 -> vcc", "v_cndmask e32 (vcc)", "s_add + literal(8B)", "s_addk (sopk)", "s_and_b64/s_bcnt1_b64", "mix 1 e32 + 1 vop3", "mix 1 vop3 + 1 salu", "v_bfe_u32 (vop3)", "v_cmp_e32+v_cndmask_e32", "v_cndmask_e64 vcc", "v_cndmask_e32 (vcc set once)", "v_cmp_e64+v_cndmask_e64 sgpr", "v_bitop3_b32", "v_lshlrev_b32_e32 const", "v_perm_b32 sgpr sel", "ds_read_u8", "ds_permute", "walk step, 26 bits/token", "1 v_cmp_e32 + 4 v_cndmask_e32", "s_or vcc + cndmask_e32 + 6 valu", "s_or sgpr + cndmask_e64 + 6 valu", "v_cmp_e32, 6 valu, cndmask_e32"};
+                                        "walk step, exit taken/8", "vop2 e32 + literal(8B)", "vop1 v_mov e32", "v_mbcnt_lo (vop3)", "v_add_u32_e64 (vop3,2op)", "v_lshl_add_u32", "v_cmp e32 -> vcc", "v_cndmask e32 (vcc)", "s_add + literal(8B)", "s_addk (sopk)", "s_and_b64/s_bcnt1_b64", "mix 1 e32 + 1 vop3", "mix 1 vop3 + 1 salu", "v_bfe_u32 (vop3)", "v_cmp_e32+v_cndmask_e32", "v_cndmask_e64 vcc", "v_cndmask_e32 (vcc set once)", "v_cmp_e64+v_cndmask_e64 sgpr", "v_bitop3_b32", "v_lshlrev_b32_e32 const", "v_perm_b32 sgpr sel", "ds_read_u8", "ds_permute", "walk step, 26 bits/token", "1 v_cmp_e32 + 4 v_cndmask_e32", "s_or vcc + cndmask_e32 + 6 valu", "s_or sgpr + cndmask_e64 + 6 valu", "v_cmp_e32, 6 valu, cndmask_e32", "decoder-like: 6 vop3+2 e32+7 salu+2 br+1 bperm"};
 // instructions per group (for the rate)
-static const int pat_insts[P_COUNT] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 1, 4, 2, 1, 1, 1, 4, 1, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 2, 4, 2, 4, 4, 2, 4, 4, 4, 1, 1, 4, 5, 8, 8, 8};
+static const int pat_insts[P_COUNT] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 1, 4, 2, 1, 1, 1, 4, 1, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 2, 4, 2, 4, 4, 2, 4, 4, 4, 1, 1, 4, 5, 8, 8, 8, 18};
 
 template <int PAT>
 __global__ void __launch_bounds__(64) bench_kernel(uint32_t iters, uint64_t *out, uint32_t seed)
@@ -267,6 +268,13 @@ __global__ void __launch_bounds__(64) bench_kernel(uint32_t iters, uint64_t *out
             asm volatile(".rept " STR(REPT) "\n\tv_cmp_lt_u32_e32 vcc, %0, %1\n\tv_add_u32_e32 %0, %4, %0\n\tv_add_u32_e32 %1, %4, %1\n\tv_add_u32_e32 %3, %4, %3\n\t"
                          "v_add_u32_e32 %0, %4, %0\n\tv_add_u32_e32 %1, %4, %1\n\tv_add_u32_e32 %3, %4, %3\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\t.endr"
                          : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "v"(v4) : "vcc");
+
+        if (PAT == P_DECODER_MIX)  // the decoder's own proportions per 18 instructions: 8 vector (6 half-rate), 7 scalar, 2 branches, 1 crossbar gather
+            asm volatile(".rept " STR(REPT) "\n\tv_alignbit_b32 %0, %6, %0, %6\n\ts_add_u32 %4, %4, %7\n\tv_bfe_u32 %1, %1, %6, %6\n\ts_add_u32 %5, %5, %7\n\t"
+                         "v_add_u32_e32 %2, %6, %2\n\ts_cmp_eq_u32 %7, -1\n\ts_cbranch_scc1 9f\n\tv_perm_b32 %3, %3, %6, %7\n\ts_and_b32 %4, %4, %7\n\t"
+                         "ds_bpermute_b32 %0, %6, %0\n\tv_mbcnt_lo_u32_b32 %1, %7, %1\n\ts_lshl_b32 %5, %5, 1\n\tv_sub_u32_e32 %2, %6, %2\n\ts_add_u32 %4, %4, %7\n\t"
+                         "v_cndmask_b32_e64 %3, %3, %6, %8\n\ts_cmp_eq_u32 %7, -2\n\ts_cbranch_scc1 9f\n\ts_or_b32 %5, %5, %7\n\t.endr\n9:\n\ts_waitcnt lgkmcnt(0)"
+                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(s0), "+s"(s1) : "v"(v4), "s"(seed), "s"(m) : "scc");
         if (PAT == P_NOP) asm volatile(".rept " STR(REPT) "\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\t.endr");
         if (PAT == P_WAIT) asm volatile(".rept " STR(REPT) "\n\ts_waitcnt lgkmcnt(0)\n\t.endr");
     }
@@ -298,7 +306,7 @@ int main(int argc, char **argv)
     printf("device %s, %d CUs, clockRate %d kHz\n", prop.name, ncu, prop.clockRate);
     kern_t tab[P_COUNT];
     fill<0>(tab);
-    const int Ws[] = {1, 4, 8, 12, 16};
+    const int Ws[] = {4, 8, 16, 24, 28};
     uint64_t *d_out;
     CK(hipMalloc(&d_out, sizeof(uint64_t) * 2 * ncu * 32));
     std::vector<uint64_t> h(2 * ncu * 32);
@@ -315,6 +323,7 @@ int main(int argc, char **argv)
             size_t ldsb = (160u * 1024u) / (size_t)W;
             if (ldsb > 64u * 1024u) ldsb = 64u * 1024u;
             ldsb &= ~(size_t)255;
+            if (getenv("IB_NO_LDS_CAP")) ldsb = 1024;  // (residency then limited by wave slots only: 8 per SIMD)
             CK(hipFuncSetAttribute((const void *)tab[p], hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
             hipLaunchKernelGGL(tab[p], dim3(grid), dim3(64), ldsb, 0, 20u, d_out, 1u);  // warm-up
             CK(hipDeviceSynchronize());

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -163,6 +164,10 @@ int main(int argc, char **argv)
     std::vector<uint64_t> h(2 * grid);
     printf("%d CUs, %d waves per CU; cycles per instruction: per SIMD (= 4 x per CU), per CU, lone-wave; clock MHz\n", ncu, W);
     for (int p = 0; p < OP_COUNT; ++p) {
+        if (argc > 3) {  // only the opcodes named in argv[3] (comma-separated, exact names)
+            const std::string want = std::string(",") + argv[3] + ",";
+            if (want.find(std::string(",") + op_name[p] + ",") == std::string::npos) continue;
+        }
         double lone = 0;
         double res[2] = {0, 0}, mhz = 0;
         for (int pass = 0; pass < 2; ++pass) {
