@@ -87,7 +87,7 @@ def test_library_reads_no_undocumented_environment_knob():
     assert set(re.findall(r"PZG_[A-Z_0-9]+", text)) == {"PZG_RING_BITS"}
     with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", "Makefile")) as f:
         assert "PZG_LAB" not in f.read()
-    for fn in ("inflate_core.h", "pzg_kernels.hip", "pzg_api.cpp"):
+    for fn in ("inflate_core.h", "pzg_kernels.hip", "pzg_api.cpp", "pzg_helpers.h"):
         with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", fn)) as f:
             src = f.read()
         assert "PZG_EXP_" not in src and "PZG_NO_SUB" not in src and "PZG_FAR_NT" not in src, fn
@@ -177,7 +177,7 @@ def noflags_library():
     library must be just as correct without them, only slower)."""
     import subprocess
     so = os.path.join(ROOT, "build", "noflags", "libpzg.so")
-    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_kernels.hip", "pzg_launch.h", "pzg_api.cpp",
+    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_kernels.hip", "pzg_launch.h", "pzg_helpers.h", "pzg_api.cpp",
                                                                     "pzg_errors.cpp", "pzg.map")] + [os.path.join(ROOT, "include", "pzg.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call([os.path.join(ROOT, "tests", "tools", "noflags_build.sh")])

@@ -34,3 +34,16 @@ def test_oracle_and_kernel_model_under_asan_ubsan(exe, rb, cap):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_helper_thread_pool_under_sanitizers(tmp_path, san):
+    """The persistent helper pool of the host-pointer paths (pure_zlib_amd/csrc/pzg_helpers.h; round 4): four threads call run()
+    at once with jobs of 1-37 parts, every part runs exactly once and its writes are visible when run() returns; under
+    ThreadSanitizer and under ASan + UBSan."""
+    out = str(tmp_path / "helpers_stress")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + san, "-fno-sanitize-recover=all", "-pthread",
+                           os.path.join(ROOT, "tests", "cxx", "helpers_stress.cpp"), "-o", out])
+    for workers in ("8", "1", "24"):
+        r = subprocess.run([out, workers, "150"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "0 error(s)" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout[-500:] + r.stderr[-3000:]
