@@ -40,6 +40,12 @@
 #define PZG_ACC(slot, var) ((slot) >= 8 && (slot) <= 11 ? (void)var : (void)(prof[slot] += __builtin_amdgcn_s_memtime() - var))
 #define PZG_ACCW(slot, var) ((void)var)
 #define PZG_HACC(slot, var) prof[slot] += __builtin_amdgcn_s_memtime() - var
+#elif defined(PZG_PROFILE) && PZG_DEVICE_PASS && defined(PZG_PROFILE_HOT)  // slots 8-10 = inside hot_loop(): windows, segments; the rare window path
+#define PZG_T0(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#define PZG_ACC(slot, var) ((slot) >= 8 && (slot) <= 11 ? (void)var : (void)(prof[slot] += __builtin_amdgcn_s_memtime() - var))
+#define PZG_ACCW(slot, var) ((void)var)
+#define PZG_HACC(slot, var)
+#define PZG_HOT_ACC(slot, var) prof[slot] += __builtin_amdgcn_s_memtime() - var
 #elif defined(PZG_PROFILE) && PZG_DEVICE_PASS
 #define PZG_T0(var) const uint64_t var = __builtin_amdgcn_s_memtime()
 #define PZG_ACC(slot, var) prof[slot] += __builtin_amdgcn_s_memtime() - var
@@ -56,6 +62,9 @@
 #define PZG_MARK(name) asm volatile("; ##MARK " name)
 #else
 #define PZG_MARK(name)
+#endif
+#ifndef PZG_HOT_ACC
+#define PZG_HOT_ACC(slot, var)
 #endif
 
 // Lab build of the HOST model only (-DPZG_STATS, tests/tools/model_stats.py): event counts of the token loop
@@ -484,6 +493,11 @@ struct Decoder {
     uint32_t lit_n, dist_n;      // symbols of the current block's two codes: lens[0..lit_n) and lens[lit_n..lit_n+dist_n)
     uint32_t use_sub;            // the block's literal/length code has enough long prefixes: windows do the second lookup
     uint32_t lit_sub_used;       // second-level entries taken by the literal/length code (the distance code's follow)
+    uint32_t dist_sub_used;      // ... by the distance code
+    // strips (strip_span): this wave's token scratch in HBM (null: no strips), the tokens of the span being emitted
+    uint32_t *strip;
+    uint32_t s_reg, s_idx, s_last;  // the queue's head is token s_idx of lane s_reg's region; s_last = the span's last region
+    LaneVec<uint32_t> SCNT;         // tokens in each lane's region
     int32_t status;
     uint32_t detail0, detail1;
     // A segment's bytes from literals and the near ring are stored at once; bytes whose source is older than
@@ -520,7 +534,7 @@ struct Decoder {
     uint64_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 0 total, 1 header+tables, 2 token loop, 3 flush, 4 window_append, 5 checked steps, 6 windows, 7 tokens queued, 8-11 emit phases, 12 emit, 13 segments, 14 general copies, 15 checked steps
 #endif
 
-    PZG_FN Decoder(WaveLds<RING_BITS> &lds) : L(lds) {}
+    PZG_FN Decoder(WaveLds<RING_BITS> &lds) : L(lds), strip(nullptr) {}
 
     // Pin every piece of wave-uniform decoder state back into SGPRs.  All of it IS uniform by
     // construction; this only tells the compiler so (v_readfirstlane of an SGPR value folds away),
@@ -545,6 +559,10 @@ struct Decoder {
         lit_n = uni(lit_n);
         use_sub = uni(use_sub);
         lit_sub_used = uni(lit_sub_used);
+        dist_sub_used = uni(dist_sub_used);
+        s_reg = uni(s_reg);
+        s_idx = uni(s_idx);
+        s_last = uni(s_last);
         dist_n = uni(dist_n);
         pend_m0 = uni64(pend_m0);
         pend_m1 = uni64(pend_m1);
@@ -1042,6 +1060,7 @@ struct Decoder {
                     sub_total = np_fit << 1;
                 }
             }
+            if (TREE == TREE_DIST) dist_sub_used = sub_total;
             if (TREE == TREE_LITLEN) {
                 lit_sub_used = sub_total;
                 use_sub = np_fit >= SUB_MIN_PREFIXES ? 1u : 0u;
@@ -1749,7 +1768,7 @@ struct Decoder {
     // FAST (hot_loop): returns EMIT_BAIL, with nothing changed that emit_segment() would not redo, where the general
     // code has lane-dependent branches -- a flush is due, or the queue's head is a match for copy_match().
     static constexpr int EMIT_BAIL = -1;
-    template <bool FAST>
+    template <bool FAST, bool STRIPQ = false>
     PZG_FN int emit_body()
     {
         PZG_MARK("e.begin");
@@ -1896,6 +1915,11 @@ struct Decoder {
             }
         }
         PZG_MARK("e.shift");
+        if (STRIPQ) {  // the span's next tokens, straight from the wave's token scratch (strip_span)
+            strip_consume(v);
+            strip_refill();
+            return ST_OK;
+        }
         // the queue moves up by v tokens
         LaneVec<uint32_t> SRC;
         PZG_LANES_BEGIN(j)
@@ -1963,6 +1987,7 @@ struct Decoder {
                     why = HL_GENERAL;
                     break;
                 }
+                PZG_T0(thw);
                 LaneVec<uint32_t> TB0, TB1;
                 window2_decode<FX, false, SUB>(TB0, TK0, TB1, TK1);
                 S0 = 0;
@@ -1979,10 +2004,346 @@ struct Decoder {
                 PZG_STAT(1, nt0 + nt1);  // tokens queued by clean windows
                 queue_append(TK0, S0, nt0, TK1, S1, nt1);
                 br.drop_short(k1 + 128u);
+                PZG_HOT_ACC(8, thw);
                 continue;
             }
+            PZG_T0(the);
             if (emit_body<true>() != ST_OK) {
                 why = HL_GENERAL;
+                break;
+            }
+            PZG_HOT_ACC(9, the);
+        }
+#if PZG_DEVICE_PASS
+        asm volatile("" : "+s"(why));
+#endif
+        return why;
+    }
+
+
+    // ---- strips (round 4): a long run of input decoded by 64 lanes side by side ------------------------------------
+    // The windows pay ~140 instructions per 128 input bits -- 128 speculative lane-decodes and a serial walk for ~12 real
+    // tokens.  A strip pays ~70 instructions for 64 REAL tokens: the input in front of the cursor is cut into 64 strips of C
+    // bits, and lane k decodes strip k token by token (the same LDS lookups and 13 vector instructions as a window's lane),
+    // reading its input through a 192-bit buffer of its own that moves on 64 bits at a time.  What a lane cannot know is where
+    // its first token starts.  Phase A: it starts STRIP_BACK bits in front of its strip at an arbitrary bit and decodes up to
+    // the strip -- DEFLATE's codes re-synchronise: by then the lane is on the stream's real chain of tokens with probability
+    // ~0.996 for text (measured: half of all wrong starts are back on the chain after 92 bits, 99 % after 630).  Phase B:
+    // every lane decodes its strip from there and stores the tokens into its own region of the wave's scratch (strip[], four
+    // tokens per store); where lane k - 1's chain leaves its strip must be where lane k started -- lanes for which that is not
+    // so decode again from the right place (and then perhaps the next lane...), at most STRIP_ROUNDS times, after which the
+    // span simply ends in front of the first lane that is still wrong.  It also ends at the first lane that met a stopper (end
+    // of block, a code the tables do not resolve, an error: token_step_checked()'s business, as with the windows) or filled
+    // its region.  emit_body() then takes its tokens from the regions, lane after lane (STRIPQ: one load instead of the queue's
+    // shift), until the span is used up.  Nothing about the result depends on the guesses: a wrong guess costs a round, never
+    // a token.
+    static constexpr bool STRIPS = !RES;
+#ifndef PZG_STRIP_TMAX
+#define PZG_STRIP_TMAX 128
+#endif
+#ifndef PZG_STRIP_BACK
+#define PZG_STRIP_BACK 768
+#endif
+    static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may store per span (a multiple of 4)
+    static constexpr uint32_t STRIP_RSTRIDE = STRIP_TMAX + 4u;  // a region: 4 words of slack (the last, partial group of four is stored
+                                                                // as the lane's last four tokens, which may reach below the region), then the tokens
+    static constexpr uint32_t STRIP_WORDS = 64u * STRIP_RSTRIDE + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
+    static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits
+    static constexpr uint32_t STRIP_CMIN = 256u;                // shorter strips are not worth a span
+    static constexpr uint32_t STRIP_ROUNDS = 6u;
+    static constexpr int STRIP_NA = -2;
+    PZG_FN static constexpr uint32_t strip_region(uint32_t k) { return k * STRIP_RSTRIDE + 4u; }
+
+    // the wave's own stores of a moment ago, read back by OTHER lanes: device-scope loads (not served from a stale L1 line)
+    PZG_FN uint32_t strip_load(uint32_t i) const
+    {
+#if PZG_DEVICE_PASS
+        return __hip_atomic_load(strip + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        return strip[i];
+#endif
+    }
+    PZG_FN void strip_fence() const
+    {
+#if PZG_DEVICE_PASS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    }
+    // the queue = the next tokens of the span: the rest of region s_reg from s_idx on, then region s_reg + 1
+    PZG_FN void strip_refill()
+    {
+        uint32_t n0 = lane_get(SCNT, s_reg) - s_idx;
+        while (n0 == 0u && s_reg < s_last) {
+            s_reg += 1u;
+            s_idx = 0u;
+            n0 = lane_get(SCNT, s_reg);
+        }
+        const uint32_t n1 = s_reg < s_last ? lane_get(SCNT, s_reg + 1u) : 0u;
+        const uint32_t a0 = strip_region(s_reg) + s_idx, a1 = strip_region(s_reg + 1u) - n0;
+        PZG_LANES_BEGIN(j)
+            PZG_LV(QT, j) = strip_load((j < n0 ? a0 : a1) + j);  // (past both regions: some word of the scratch, never looked at)
+        PZG_LANES_END
+        const uint32_t left = n0 + n1;
+        qn = left < QCAP ? left : QCAP;
+    }
+    PZG_FN void strip_consume(uint32_t v)
+    {
+        s_idx += v;
+        uint32_t n = lane_get(SCNT, s_reg);
+        if (s_idx >= n && s_reg < s_last) {  // (v <= qn <= the rest of this region + the next one)
+            s_idx -= n;
+            s_reg += 1u;
+        }
+    }
+    // the distance code's second level, as spec_sub() for the literal/length code (a distance base can have bit 30 set,
+    // so K_SUB is recognised by its stop bit and kind)
+    PZG_FN void spec_dsub(Spec &t)
+    {
+        const bool is_sub = (t.d & 0x780u) == 0x780u;
+        const uint32_t off = ((t.d >> 14) & 0x3fcu) + (ubfe(t.w2, DIST_BITS, t.d) << 2);
+#if PZG_DEVICE_PASS
+        uint32_t d2 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(L.sub) + off);
+        asm("" : "+v"(d2));
+#else
+        const uint32_t d2 = is_sub ? L.sub[off >> 2] : 0u;
+#endif
+        t.d = is_sub ? d2 : t.d;
+    }
+    // A lane's reader: b0..b5 = the six dwords from dword 2 * g of the span on, r = the lane's position relative to b0's
+    // bit 0 (below 64 between steps), nx = the next pair of dwords to fetch.  A token is at most 48 bits: r + 48 <= 112, so b0..b3
+    // hold it; b4, b5 are the fetch in flight.  (Pairs past `maxdw` -- the stream's last dwords -- repeat that pair: no token
+    // of a span reaches there.)
+    struct StripReader {
+        LaneVec<uint32_t> B0, B1, B2, B3, B4, B5, R, NX;
+    };
+    PZG_FN static uint32_t strip_dw(const uint32_t *sp, uint32_t i) { return sp[i]; }
+#define PZG_SR(f) PZG_LV(rd.f, k)
+    // one lane's token at its position: tb = its bits (>= 128: a stopper), tk = the token
+    template <bool FX>
+    PZG_FN void strip_token(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t r, bool lsub, bool dsub, uint32_t &tb, uint32_t &tk)
+    {
+        const bool up = r >= 32u;
+        Spec t;
+        spec_bits<FX>(t, up ? b1 : b0, up ? b2 : b1, up ? b3 : b2, r);  // (the funnel shifts take r modulo 32)
+        if (!FX && lsub) spec_sub(t);  // (wave-uniform)
+        spec_dist<FX>(t);
+        if (!FX && dsub) spec_dsub(t);
+        spec_finish(t, tb, tk);
+    }
+
+    // Decodes and emits one span.  STRIP_NA: nothing done (too little input ahead; the windows take over);
+    // ST_OK: the span's tokens are all out, the cursor stands behind them -- at a stopper if `stopper`; else an error status.
+    template <bool FX>
+    PZG_FN int strip_span(bool &stopper)
+    {
+        stopper = false;
+        const int64_t av = br.avail();
+        if (av < (int64_t)(64u * STRIP_CMIN + 192u)) return STRIP_NA;
+        // no strip holds more tokens than its bits / the block's shortest literal/length code
+        uint32_t minlen = 7u;
+        if (!FX) {
+            minlen = 1u;
+            while (minlen < 15u && uni(L.lit_meta.count[minlen]) == 0u) ++minlen;
+        }
+        const uint64_t cav = ((uint64_t)av - 192u) >> 6;  // the last strip ends 192 bits or more in front of the stream's end
+        uint32_t C = cav > 4096u ? 4096u : (uint32_t)cav;
+        if (C > STRIP_TMAX * minlen) C = STRIP_TMAX * minlen;
+        if (C < STRIP_CMIN) return STRIP_NA;
+        while (qn != 0u) {  // (tokens a checked step queued: they go first)
+            const int se = emit_segment();
+            if (se) return se;
+        }
+        const uint64_t pos0 = br.pos();
+        const uint32_t r0 = (uint32_t)pos0 & 31u;
+        const uint32_t dw0 = (uint32_t)(pos0 >> 5);
+        const uint32_t *sp = br.base + dw0;
+        const uint32_t maxdw = (br.ndw - dw0 - 2u) & ~1u;
+        const uint64_t bit0 = stream_bit_pos();
+        const bool lsub = !FX && lit_sub_used != 0u, dsub = !FX && dist_sub_used != 0u;
+        PZG_T0(tsa);
+        // phase A: the run-up
+        StripReader rd;
+        LaneVec<uint32_t> P, S, LIM;
+        PZG_LANES_BEGIN(k)
+            const uint32_t lo = k * C;
+            PZG_LV(LIM, k) = r0 + lo;
+            const uint32_t p = r0 + (lo > STRIP_BACK ? lo - STRIP_BACK : 0u);  // (from the cursor itself: exact)
+            PZG_LV(P, k) = p;
+            const uint32_t g2 = (p >> 6) << 1;
+            const uint32_t i0 = g2 < maxdw ? g2 : maxdw, i1 = g2 + 2u < maxdw ? g2 + 2u : maxdw, i2 = g2 + 4u < maxdw ? g2 + 4u : maxdw;
+            PZG_SR(B0) = sp[i0]; PZG_SR(B1) = sp[i0 + 1u];
+            PZG_SR(B2) = sp[i1]; PZG_SR(B3) = sp[i1 + 1u];
+            PZG_SR(B4) = sp[i2]; PZG_SR(B5) = sp[i2 + 1u];
+            PZG_SR(R) = p & 63u;
+            PZG_SR(NX) = g2 + 6u;
+        PZG_LANES_END
+        for (;;) {
+            LaneVec<bool> ACT;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(ACT, k) = PZG_LV(P, k) < PZG_LV(LIM, k);
+            PZG_LANES_END
+            if (lanes_ballot(ACT) == 0ull) break;
+            PZG_LANES_BEGIN(k)
+                uint32_t tb, tk;
+                strip_token<FX>(PZG_SR(B0), PZG_SR(B1), PZG_SR(B2), PZG_SR(B3), PZG_SR(R), lsub, dsub, tb, tk);
+                const uint32_t adv = PZG_LV(ACT, k) ? (tb < 128u ? tb : 1u) : 0u;  // (no token here: this is not the chain yet)
+                PZG_LV(P, k) += adv;
+                PZG_SR(R) += adv;
+                if (PZG_SR(R) >= 64u) {
+                    const uint32_t i = PZG_SR(NX) < maxdw ? PZG_SR(NX) : maxdw;
+                    PZG_SR(B0) = PZG_SR(B2); PZG_SR(B1) = PZG_SR(B3); PZG_SR(B2) = PZG_SR(B4); PZG_SR(B3) = PZG_SR(B5);
+                    PZG_SR(B4) = sp[i]; PZG_SR(B5) = sp[i + 1u];
+                    PZG_SR(NX) += 2u;
+                    PZG_SR(R) -= 64u;
+                }
+            PZG_LANES_END
+            PZG_STAT(16, 1);  // steps of phase A
+        }
+        // phase B: the strips, until every lane started where its neighbour ended
+        PZG_HOT_ACC(8, tsa);
+        PZG_T0(tsb);
+        LaneVec<uint32_t> N, STF, T0, T1, T2, T3;  // tokens stored; 1 = met a stopper, 2 = region full; the last four tokens
+        PZG_LANES_BEGIN(k)
+            PZG_LV(S, k) = PZG_LV(P, k);
+            PZG_LV(LIM, k) += C;
+            PZG_LV(N, k) = 0u;
+            PZG_LV(STF, k) = 0u;
+            PZG_LV(T0, k) = PZG_LV(T1, k) = PZG_LV(T2, k) = PZG_LV(T3, k) = 0u;
+        PZG_LANES_END
+        uint64_t dirty = ~0ull, stopm = 0ull;
+        uint32_t last = 63u;
+        for (uint32_t round = 0;;) {
+            if (round != 0u) {  // the lanes that start again, from where their neighbour's chain arrived
+                PZG_LANES_BEGIN(k)
+                    if (lane_bit(dirty, k)) {
+                        const uint32_t p = PZG_LV(S, k);
+                        PZG_LV(P, k) = p;
+                        PZG_LV(N, k) = 0u;
+                        PZG_LV(STF, k) = 0u;
+                        const uint32_t g2 = (p >> 6) << 1;
+                        const uint32_t i0 = g2 < maxdw ? g2 : maxdw, i1 = g2 + 2u < maxdw ? g2 + 2u : maxdw, i2 = g2 + 4u < maxdw ? g2 + 4u : maxdw;
+                        PZG_SR(B0) = sp[i0]; PZG_SR(B1) = sp[i0 + 1u];
+                        PZG_SR(B2) = sp[i1]; PZG_SR(B3) = sp[i1 + 1u];
+                        PZG_SR(B4) = sp[i2]; PZG_SR(B5) = sp[i2 + 1u];
+                        PZG_SR(R) = p & 63u;
+                        PZG_SR(NX) = g2 + 6u;
+                    }
+                PZG_LANES_END
+            }
+            for (;;) {
+                LaneVec<bool> ACT;
+                PZG_LANES_BEGIN(k)
+                    PZG_LV(ACT, k) = lane_bit(dirty, k) & (PZG_LV(STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k));
+                PZG_LANES_END
+                if (lanes_ballot(ACT) == 0ull) break;
+                PZG_LANES_BEGIN(k)
+                    uint32_t tb, tk;
+                    strip_token<FX>(PZG_SR(B0), PZG_SR(B1), PZG_SR(B2), PZG_SR(B3), PZG_SR(R), lsub, dsub, tb, tk);
+                    const bool act = PZG_LV(ACT, k), full = PZG_LV(N, k) >= STRIP_TMAX, stop = tb >= 128u;
+                    const bool ok = act & !stop & !full;
+                    PZG_LV(STF, k) = (act & stop) ? 1u : (act & full) ? 2u : PZG_LV(STF, k);
+                    PZG_LV(T0, k) = ok ? PZG_LV(T1, k) : PZG_LV(T0, k);
+                    PZG_LV(T1, k) = ok ? PZG_LV(T2, k) : PZG_LV(T1, k);
+                    PZG_LV(T2, k) = ok ? PZG_LV(T3, k) : PZG_LV(T2, k);
+                    PZG_LV(T3, k) = ok ? tk : PZG_LV(T3, k);
+                    PZG_LV(N, k) += ok ? 1u : 0u;
+                    const uint32_t adv = ok ? tb : 0u;
+                    PZG_LV(P, k) += adv;
+                    PZG_SR(R) += adv;
+                    if (ok & ((PZG_LV(N, k) & 3u) == 0u)) {  // four more tokens: one 16-byte store
+                        uint32_t *q = strip + strip_region(k) + PZG_LV(N, k) - 4u;
+                        q[0] = PZG_LV(T0, k); q[1] = PZG_LV(T1, k); q[2] = PZG_LV(T2, k); q[3] = PZG_LV(T3, k);
+                    }
+                    if (PZG_SR(R) >= 64u) {
+                        const uint32_t i = PZG_SR(NX) < maxdw ? PZG_SR(NX) : maxdw;
+                        PZG_SR(B0) = PZG_SR(B2); PZG_SR(B1) = PZG_SR(B3); PZG_SR(B2) = PZG_SR(B4); PZG_SR(B3) = PZG_SR(B5);
+                        PZG_SR(B4) = sp[i]; PZG_SR(B5) = sp[i + 1u];
+                        PZG_SR(NX) += 2u;
+                        PZG_SR(R) -= 64u;
+                    }
+                PZG_LANES_END
+                PZG_STAT(17, 1);  // steps of phase B
+            }
+            // the last, partial group of every lane that ran: its last four tokens, wherever they end
+            PZG_LANES_BEGIN(k)
+                if (lane_bit(dirty, k)) {
+                    uint32_t *q = strip + strip_region(k) + PZG_LV(N, k) - 4u;
+                    q[0] = PZG_LV(T0, k); q[1] = PZG_LV(T1, k); q[2] = PZG_LV(T2, k); q[3] = PZG_LV(T3, k);
+                }
+            PZG_LANES_END
+            // lane k must have started where lane k - 1's chain left its strip; lanes behind the first one that stopped do not count
+            LaneVec<uint32_t> NS, PREV;
+            LaneVec<bool> BAD, STOPPED;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(PREV, k) = k - 1u;
+                PZG_LV(STOPPED, k) = PZG_LV(STF, k) != 0u;
+            PZG_LANES_END
+            lanes_gather(NS, P, PREV);
+            stopm = lanes_ballot(STOPPED);
+            last = stopm ? ctz64(stopm) : 63u;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(BAD, k) = (k != 0u) & (k <= last) & (PZG_LV(NS, k) != PZG_LV(S, k));
+            PZG_LANES_END
+            dirty = lanes_ballot(BAD);
+            PZG_STAT(15, 1);  // rounds of phase B
+            if (dirty == 0ull || ++round >= STRIP_ROUNDS) break;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(S, k) = PZG_LV(BAD, k) ? PZG_LV(NS, k) : PZG_LV(S, k);
+            PZG_LANES_END
+        }
+        if (dirty != 0ull) {  // still a lane that started in the wrong place: the span ends in front of it
+            last = ctz64(dirty) - 1u;
+            stopm = 0ull;
+        }
+        stopper = stopm != 0ull && lane_get(STF, last) == 1u;
+        const uint32_t pend = lane_get(P, last);
+        PZG_HOT_ACC(9, tsb);
+        PZG_T0(tsc);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(SCNT, k) = k <= last ? PZG_LV(N, k) : 0u;
+        PZG_LANES_END
+        s_reg = 0u;
+        s_idx = 0u;
+        s_last = last;
+#if defined(PZG_STATS) && !PZG_DEVICE_PASS
+        {
+            uint32_t tot = 0;
+            for (uint32_t k = 0; k <= last; ++k) tot += lane_get(SCNT, k);
+            PZG_STAT(13, 1);                 // spans
+            PZG_STAT(14, tot);               // their tokens
+            PZG_STAT(18, dirty != 0ull ? 1 : 0);
+            PZG_STAT(19, last + 1u);         // lanes that counted
+        }
+#endif
+        // the cursor goes behind the span
+        const uint64_t endbit = bit0 + (uint64_t)(pend - r0);
+        in_byte0 = endbit >> 3;
+        br.start(in, in_len, in_byte0);
+        br.drop((uint32_t)endbit & 7u);
+        strip_fence();
+        strip_refill();
+        PZG_HOT_ACC(10, tsc);
+        PZG_T0(tse);
+        // segments for as long as tokens are left (the fast body in a loop of its own: see hot_loop())
+        for (;;) {
+            if (strip_hot() == 0u) break;
+            const int se = emit_body<false, true>();
+            if (se) return se;
+        }
+        PZG_HOT_ACC(11, tse);
+        return ST_OK;
+    }
+#undef PZG_SR
+    PZG_FN uint32_t strip_hot()
+    {
+        uint32_t why;
+        for (;;) {
+            if (qn == 0u) {
+                why = 0u;
+                break;
+            }
+            if (emit_body<true, true>() != ST_OK) {
+                why = 1u;
                 break;
             }
         }
@@ -1995,17 +2356,29 @@ struct Decoder {
     template <bool FX>
     PZG_FN int token_loop()
     {
+        bool strips = STRIPS && strip != nullptr;
         for (;;) {
             PZG_T0(tw);
             bool checked;
+            bool span_done = false;
+            if (strips) {
+                const int ss = strip_span<FX>(checked);
+                if (ss == STRIP_NA) strips = false;
+                else if (ss != ST_OK) return ss;
+                else if (!checked) continue;
+                else span_done = true;
+            }
+            if (!span_done) {
             uint32_t why = HL_GENERAL;
             LaneVec<uint32_t> TK0, TK1;
             uint64_t S0 = 0, S1 = 0;
             uint32_t k0 = 0, k1 = 0;
             if (!RES) why = FX ? hot_loop<FX, 0>(TK0, TK1, S0, S1, k0, k1) : use_sub ? hot_loop<FX, 1>(TK0, TK1, S0, S1, k0, k1)
                                                                                        : hot_loop<FX, 0>(TK0, TK1, S0, S1, k0, k1);
+            PZG_T0(trw);
             if (why == HL_WINDOW) checked = window2_rare(TK0, TK1, S0, S1, k0, k1);
             else checked = qn < QHIGH && fill_queue<FX>();
+            PZG_HOT_ACC(10, trw);
             PZG_ACC(4, tw);
             if (!checked) {
                 PZG_T0(te);
@@ -2013,6 +2386,7 @@ struct Decoder {
                 PZG_ACC(12, te);
                 if (se) return se;
                 continue;
+            }
             }
             PZG_T0(tc);
             const int st = token_step_checked<FX>();
@@ -2309,6 +2683,8 @@ struct Decoder {
         lit_n = dist_n = 0;
         use_sub = 0;
         lit_sub_used = 0;
+        dist_sub_used = 0;
+        s_reg = s_idx = s_last = 0;
         pend_m0 = pend_m1 = 0;
         pend_pos = 0;
         qn = 0;

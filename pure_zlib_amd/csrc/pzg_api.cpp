@@ -50,6 +50,7 @@ struct Pinned {
 
 constexpr uint32_t ADLER_MAX_WAVES = 8192;  // 256 CUs x 32 waves
 constexpr int LANES_PER_SHARD = 4;
+constexpr int STRIP_SLOTS = 2;
 constexpr int COUNTER_SLOTS = 16;           // device-pointer launches in flight on one shard, each with its own counter
 constexpr size_t RANGE_MAX_OUT = 256ull << 20;  // a range's packed output stays below this (bounds the pinned staging)
 
@@ -59,6 +60,7 @@ struct Lane {
     hipEvent_t ev_up[NSLOT] = {}, ev_k[NSLOT] = {}, ev_dn[NSLOT] = {};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // first / last kernel of the call this lane is running (pzg_last_kernel_ms)
     Arena d_in[NSLOT], d_out[NSLOT], d_meta[NSLOT], d_gz[NSLOT], d_ord[NSLOT];
+    Arena d_strip;  // the kernels' token scratch: the lane's launches all go to s_k, one after the other
     Pinned h_in[NSLOT], h_out[NSLOT], h_meta[NSLOT];
     uint32_t *d_counter = nullptr;
     std::mutex mu;
@@ -81,6 +83,12 @@ struct Shard {
     std::atomic<uint32_t> next_counter{0};
     Arena a_adler, a_scratch, a_dec;
     Arena a_gz[COUNTER_SLOTS], a_order[COUNTER_SLOTS];
+    // ... and the kernels' token scratch (hundreds of MiB for a launch that fills the chip): STRIP_SLOTS of them, a launch
+    // that takes one in use waits (on its own stream) for the launch that used it last
+    Arena a_strip[STRIP_SLOTS];
+    hipEvent_t ev_strip[STRIP_SLOTS] = {};
+    bool strip_used[STRIP_SLOTS] = {};
+    uint32_t next_strip = 0;
     Lane lanes[LANES_PER_SHARD];
     std::atomic<uint32_t> next_lane{0};
     std::mutex mu;  // device-pointer path bookkeeping (stream pointer, arenas above, timing events)
@@ -210,6 +218,7 @@ void lane_destroy(Lane &ln)
     if (ln.ev_t0) (void)hipEventDestroy(ln.ev_t0);
     if (ln.ev_t1) (void)hipEventDestroy(ln.ev_t1);
     if (ln.d_counter) (void)hipFree(ln.d_counter);
+    if (ln.d_strip.p) (void)hipFree(ln.d_strip.p);
     if (ln.s_k) (void)hipStreamDestroy(ln.s_k);
     if (ln.s_up) (void)hipStreamDestroy(ln.s_up);
     if (ln.s_dn) (void)hipStreamDestroy(ln.s_dn);
@@ -235,6 +244,8 @@ int shard_create(pzg_ctx *ctx, int device, std::unique_ptr<Shard> &out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) sh->num_cus = prop.multiProcessorCount;
     if (hipMalloc((void **)&sh->d_counters, 256 * COUNTER_SLOTS) != hipSuccess) return PZG_RC_NO_MEMORY;
+    for (int k = 0; k < STRIP_SLOTS; ++k)
+        if (hipEventCreateWithFlags(&sh->ev_strip[k], hipEventDisableTiming) != hipSuccess) return PZG_RC_NO_DEVICE;
     out = std::move(sh);
     (void)ctx;
     return PZG_RC_OK;
@@ -250,6 +261,10 @@ void shard_destroy(Shard &sh)
     for (int k = 0; k < COUNTER_SLOTS; ++k)
         for (Arena *a : {&sh.a_gz[k], &sh.a_order[k]})
             if (a->p) (void)hipFree(a->p);
+    for (int k = 0; k < STRIP_SLOTS; ++k) {
+        if (sh.a_strip[k].p) (void)hipFree(sh.a_strip[k].p);
+        if (sh.ev_strip[k]) (void)hipEventDestroy(sh.ev_strip[k]);
+    }
     if (sh.d_counters) (void)hipFree(sh.d_counters);
     if (sh.ev0) (void)hipEventDestroy(sh.ev0);
     if (sh.ev1) (void)hipEventDestroy(sh.ev1);
@@ -315,9 +330,17 @@ int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
 #if defined(PZG_PROFILE)
     a.prof_out = (uint64_t *)ctx->prof_buf;
 #endif
+    // the kernels' token scratch: the next of STRIP_SLOTS arenas, after the launch that used it last (no scratch, no strips:
+    // the kernels then decode by windows alone -- slower, never wrong)
+    const uint32_t ss = sh.next_strip++ % STRIP_SLOTS;
+    if (sh.strip_used[ss]) HIP_TRY(ctx, hipStreamWaitEvent(sh.stream, sh.ev_strip[ss], 0));
+    if (arena_reserve(ctx, sh.a_strip[ss], pzg::inflate_strip_bytes(ctx->ring_bits, sh.num_cus, a.n, a.gzip)) == PZG_RC_OK)
+        a.strip = (uint32_t *)sh.a_strip[ss].p;
     HIP_TRY(ctx, hipEventRecord(sh.ev0, sh.stream));
     HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, sh.stream));
     HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
+    HIP_TRY(ctx, hipEventRecord(sh.ev_strip[ss], sh.stream));
+    sh.strip_used[ss] = true;
     sh.timed = true;
     sh.last_was_host = false;
     if (!(flags & PZG_ASYNC)) HIP_TRY(ctx, hipStreamSynchronize(sh.stream));
@@ -462,6 +485,9 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         if ((b.flags & PZG_GZIP) && (rc = arena_reserve(ctx, ln.d_gz[s], 8 * max_n + 64)) != PZG_RC_OK) return rc;
         if ((rc = pinned_reserve(ctx, ln.h_meta[s], meta_bytes + 64)) != PZG_RC_OK) return rc;
     }
+    uint32_t *d_strip = nullptr;  // (all launches of the call go to s_k, one after the other: one scratch)
+    if (arena_reserve(ctx, ln.d_strip, pzg::inflate_strip_bytes(ctx->ring_bits, sh.num_cus, (uint32_t)max_n, (b.flags & PZG_GZIP) ? 1u : 0u)) == PZG_RC_OK)
+        d_strip = (uint32_t *)ln.d_strip.p;
     const unsigned helpers = (!pinned && (tot_in + tot_out) >= (32ull << 20)) ? ctx->helpers->size() : 1u;
 
     auto meta_ptrs = [&](uint8_t *base, size_t nn, uint64_t *&ioff, uint64_t *&ilen, uint64_t *&ooff, uint64_t *&ocap, uint64_t *&olen,
@@ -633,6 +659,7 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         a.detail = det;
         a.n = (uint32_t)nn;
         a.counter = ln.d_counter;
+        a.strip = d_strip;
         if (b.flags & PZG_GZIP) {
             a.gzip = 1;
             a.gz_expect = (uint32_t *)ln.d_gz[s].p;
@@ -758,6 +785,7 @@ int dict_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint8_t *dict_b
     a.detail = a.adler + n;
     a.n = n;
     a.counter = ln.d_counter;
+    if (arena_reserve(ctx, ln.d_strip, pzg::inflate_strip_bytes(ctx->ring_bits, sh.num_cus, n, 0u)) == PZG_RC_OK) a.strip = (uint32_t *)ln.d_strip.p;
     HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, st));
     std::vector<uint8_t> res(32 * (size_t)n), hout(op + 16);
     HIP_TRY(ctx, hipMemcpyAsync(res.data(), dm + 48 * (size_t)n, 32 * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_k
             // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
             if (FIXUP && a->status[i] != ST_RETRY_FULL_RING) continue;
             Decoder<RING_BITS, GZIP> dec(lds);
+            if (!FIXUP && a->strip) dec.strip = a->strip + (size_t)blockIdx.x * Decoder<RING_BITS, GZIP>::STRIP_WORDS;
             const uint8_t *dict = nullptr;
             uint32_t dict_len = 0;
             if (!GZIP && a->dict_len) {  // extension (PZG_FDICT): this stream's preset dictionary, if it has one
@@ -340,20 +341,30 @@ __global__ __launch_bounds__(64 * CRC_WAVES) void crc32_verify_kernel(InflateArg
     }
 }
 
+// stream-waves of a launch: the residency of the chip, or one per stream if there are fewer
+static uint32_t launch_waves(int ring_bits, int num_cus, uint32_t n, uint32_t gzip)
+{
+    // Resident stream-waves per CU: 4 / 8 / 13 / 20 / 26 for rings 15 .. 11 (LDS-bound; ring 11: 72 VGPRs, 7 per SIMD by registers)
+    const uint32_t per_cu = ring_bits == 15 ? waves_per_cu<15>() : ring_bits == 14 ? waves_per_cu<14>()
+                            : ring_bits == 13 ? waves_per_cu<13>() : ring_bits == 12 ? waves_per_cu<12>()
+                            : gzip ? waves_per_cu<11, true>() : waves_per_cu<11>();
+    uint32_t waves = (uint32_t)num_cus * per_cu;
+#if defined(PZG_LAB)   // lab builds only (tests/tools/exp_build.sh -DPZG_LAB): the residency sweep
+    if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);
+#endif
+    return waves > n ? n : waves;
+}
+size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip)
+{
+    return (size_t)launch_waves(ring_bits, num_cus, n, gzip) * Decoder<11>::STRIP_WORDS * sizeof(uint32_t);
+}
+
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back
     if (e != hipSuccess) return e;
-    // Resident stream-waves per CU: 4 / 8 / 13 / 20 / 26 for rings 15 .. 11 (LDS-bound; ring 11: 72 VGPRs, 7 per SIMD by registers)
-    const uint32_t per_cu = ring_bits == 15 ? waves_per_cu<15>() : ring_bits == 14 ? waves_per_cu<14>()
-                            : ring_bits == 13 ? waves_per_cu<13>() : ring_bits == 12 ? waves_per_cu<12>()
-                            : a.gzip ? waves_per_cu<11, true>() : waves_per_cu<11>();
-    uint32_t waves = (uint32_t)num_cus * per_cu;
-#if defined(PZG_LAB)   // lab builds only (tests/tools/exp_build.sh -DPZG_LAB): the residency sweep
-    if (const char *e = getenv("PZG_WAVES")) waves = (uint32_t)atoi(e);
-#endif
-    if (waves > a.n) waves = a.n;
+    const uint32_t waves = launch_waves(ring_bits, num_cus, a.n, a.gzip);
     dim3 grid(waves), block(64);
     // Ring size classes.  15: the whole 32 KiB DEFLATE window is an LDS ring (4 stream-waves per CU).
     // 12-14: a smaller near ring plus far back-references served from the stream's own flushed output

@@ -27,6 +27,9 @@ struct InflateArgs {
     const uint8_t *dict_base;
     const uint64_t *dict_off;
     const uint64_t *dict_len;
+    // token scratch of the launch's stream-waves (inflate_core.h strip_span): inflate_strip_bytes() bytes, or null -- the
+    // kernels then decode by windows alone.  Must not be shared with a launch that may run at the same time.
+    uint32_t *strip;
 };
 
 // one batched call of the resumable decoder (decompressIncremental): decoder i continues from its ResumeState
@@ -60,6 +63,7 @@ size_t resume_state_bytes();   // one decoder's slot: ResumeState + LDS image
 size_t resume_scalar_bytes();  // ... its ResumeState part (zeroing it makes the decoder fresh)
 
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);
+size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip);  // what InflateArgs::strip must hold for that launch
 
 // partials: 3 * 4 * ceil(max_waves / 4) uint32 of device scratch
 hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *partials, uint32_t max_waves,

@@ -37,7 +37,12 @@ static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t c
     if (in_len) memcpy(buf + 8, in, in_len);
     pzg::Decoder<RB, GZ> dec(*lds);
     pzg::StreamResult sr;
+    // the wave's token scratch (strips); PZM_NO_STRIPS=1 in the environment: the windows alone, as on a launch without scratch
+    uint32_t *strip = getenv("PZM_NO_STRIPS") ? nullptr : (uint32_t *)malloc(sizeof(uint32_t) * pzg::Decoder<RB, GZ>::STRIP_WORDS);
+    if (strip) memset(strip, 0xC3, sizeof(uint32_t) * pzg::Decoder<RB, GZ>::STRIP_WORDS);
+    dec.strip = strip;
     dec.run(buf + 8, in_len, out, cap, &sr);
+    free(strip);
     r->status = sr.status;
     r->detail0 = sr.detail0;
     r->detail1 = sr.detail1;

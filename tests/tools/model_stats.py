@@ -13,7 +13,8 @@ import corpus  # noqa: E402
 
 NAMES = ["windows (hot loop)", "tokens queued by clean windows", "segments", "segments in the fast body", "ended by the 128-byte limit",
          "ended by a source inside the segment", "ended by the queue running out", "sum of qn at segment start", "bytes of segments",
-         "tokens of segments", "segments with a second pass", "head token for copy_match / bail", "checked steps"]
+         "tokens of segments", "segments with a second pass", "head token for copy_match / bail", "checked steps",
+         "strip spans", "tokens of strip spans", "phase-B rounds", "phase-A steps", "phase-B steps", "spans cut at a wrong start", "lanes that counted"]
 
 
 def build():

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import corpus
 from pure_zlib_amd import _ffi
-_ffi.LIB_PATH = os.path.join(ROOT, "build", "prof", "libpzg.so")
+_ffi.LIB_PATH = os.environ.get("PZG_PROF_LIB", os.path.join(ROOT, "build", "prof", "libpzg.so"))
 import pure_zlib_amd as P
 ctx = P.Context(0)
 L = _ffi.lib()
@@ -45,6 +45,8 @@ names = ["total", "header+tables", "token loop", "flush+adler", "window_append",
          "  emit: complete_pending", "  emit: scan+stop", "  complete_pending: wait for far bytes", "  emit: far", "emit_segment", "#segments", "#general copies", "#checked steps"]
 if os.environ.get("PZG_PROF_HDR"):
     names[8:12] = hdr
+if os.environ.get("PZG_PROF_HOT"):  # -DPZG_PROFILE_HOT build
+    names[8:12] = ["  hot loop: windows / strips: phase A", "  hot loop: segments / strips: phase B", "  rare window path / strips: compaction", "  strips: emission"]
 for i, nme in enumerate(names):
     if nme == "-":
         continue
