@@ -498,6 +498,8 @@ struct Decoder {
     uint32_t *strip;
     uint32_t s_reg, s_idx, s_last;  // the queue's head is token s_idx of lane s_reg's region; s_last = the span's last region
     LaneVec<uint32_t> SCNT;         // tokens in each lane's region
+    LaneVec<uint32_t> QTN;          // the queue after the segment in progress (strip_refill)
+    uint32_t s_qn;
     int32_t status;
     uint32_t detail0, detail1;
     // A segment's bytes from literals and the near ring are stored at once; bytes whose source is older than
@@ -511,6 +513,7 @@ struct Decoder {
     uint8_t *hist;
     const uint8_t *far_base;    // far reads: far_base + 32768 is produced-byte `flushed` (or the input, see set_far_base)
     uint64_t far_okmask;        // all ones while far reads may touch the output (128 <= flushed < cap), else 0
+    uint32_t fence_due;         // flush stores may still be on their way: the next far read waits for them (far_fence)
     // What a lane with no far source reads (the far load is unconditional: see segment_store): a byte one whole cache
     // line or more below `flushed` -- or the stream's first input byte while nothing may be read from the output.
     static constexpr uint32_t FAR_IDLE = 32768u - 128u;
@@ -563,12 +566,14 @@ struct Decoder {
         s_reg = uni(s_reg);
         s_idx = uni(s_idx);
         s_last = uni(s_last);
+        s_qn = uni(s_qn);
         dist_n = uni(dist_n);
         pend_m0 = uni64(pend_m0);
         pend_m1 = uni64(pend_m1);
         pend_pos = uni(pend_pos);
         hist_extra = uni(hist_extra);
         far_okmask = uni64(far_okmask);
+        fence_due = uni(fence_due);
         qn = uni(qn);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
@@ -756,6 +761,7 @@ struct Decoder {
         const bool ok = flushed < cap && flushed >= 128u;  // (below 2 KiB of output nothing is far anyway)
         far_base = ok ? out + (flushed - 32768u) : in - FAR_IDLE;
         far_okmask = ok ? ~0ull : 0ull;
+        fence_due = 1u;  // (called after every flush)
     }
 
     // store the last segment's far bytes (see pend_m0), then flush if due: from here on every byte below `op` is in the ring
@@ -821,10 +827,17 @@ struct Decoder {
     PZG_FN uint8_t fetch_near(uint32_t back) const { return L.ring[((uint32_t)op - back) & RMASK]; }
     // Before far reads: every flush store of this wave must have landed.  By the time a byte is older
     // than the ring its flush is long complete, so this wait is normally free.
-    PZG_FN void far_fence() const
+    // (Only the first far read after a flush has anything to wait for: with the strips' token loads in flight an unconditional
+    // wait would stall every segment that has a far byte.)
+    PZG_FN void far_fence()
     {
 #if PZG_DEVICE_PASS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (RES) {  // (the resumable instance, at the limit of its registers, keeps the plain wait)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (fence_due) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fence_due = 0u;
+        }
 #endif
     }
     PZG_FN uint8_t fetch_far(bool is_far, uint32_t back) const
@@ -1711,7 +1724,11 @@ struct Decoder {
             const uint32_t o = o0 + j;
             ring_store((o < run) & !lane_bit(farm, j), (op32 + o) & RMASK, (uint8_t)PZG_LV(VAL, j), j);
         PZG_LANES_END
+#if defined(PZG_LAB_NOFAR)  // lab timing experiment only (wrong bytes): what the far loads cost
+        if (false) {
+#else
         if (HYBRID) {  // sources older than the ring: the stream's own flushed output (fdelta = op - flushed)
+#endif
             if (RES_HIST) {  // the decoder's history, by position modulo its size
                 PZG_LANES_BEGIN(j)
                     const uint32_t hp = lane_bit(farm, j) ? (op32 + (o0 + j) - PZG_LV(DIST, j)) & HIST_MASK : 0u;
@@ -1775,8 +1792,11 @@ struct Decoder {
         PZG_T0(t_a);
         // the previous segment's bytes must all be in the ring from here on
         if (FAST) {
-            pending_stores();
+            // (the far bytes of the last segment are waited for as late as possible -- in front of this segment's first ring read:
+            // the scan below needs none of them; the resumable instance, at the limit of its registers, keeps the old order)
+            if (RES) pending_stores();
             if (__builtin_expect((uint32_t)(op - flushed) >= FLUSH_AT, 0)) {  // whole KiB only (the general flush goes up to op & ~15)
+                pending_stores();
                 const uint64_t to = flushed + ((uint32_t)(op - flushed) & ~1023u);
                 if (!out_aligned() || to > cap) return EMIT_BAIL;
                 flush_span<true>(to);
@@ -1829,6 +1849,12 @@ struct Decoder {
 #endif
         PZG_MARK("e.v");
         PZG_ACCW(9, t_b);
+#if PZG_STRIP_PREFETCH
+        if (STRIPQ && v != 0u) {
+            strip_consume(v);
+            strip_refill();
+        }
+#endif
         if (__builtin_expect(v == 0u, 0)) {
             PZG_STAT(11, 1);  // a head token for copy_match (or a bail-out of the fast body)
             if (FAST) return EMIT_BAIL;
@@ -1840,6 +1866,12 @@ struct Decoder {
             copy_match(dist, len);
             maybe_flush();
             v = 1u;
+#if PZG_STRIP_PREFETCH
+            if (STRIPQ) {
+                strip_consume(1u);
+                strip_refill();
+            }
+#endif
             if (RES) account_tokens(len, 1u, true);
         } else {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
@@ -1850,6 +1882,7 @@ struct Decoder {
             PZG_STAT(8, run);   // bytes of non-degenerate segments
             PZG_STAT(9, v);     // their tokens
             PZG_STAT(10, run > 64u ? 1 : 0);
+            if (FAST && !RES) pending_stores();
             if (run == v) {
                 // one byte per token: nothing but literals (a match is three bytes or more).  Byte j IS token j's byte:
                 // no announcements, no gathers -- literal-heavy data (little or no redundancy) spends its time here.
@@ -1915,9 +1948,12 @@ struct Decoder {
             }
         }
         PZG_MARK("e.shift");
-        if (STRIPQ) {  // the span's next tokens, straight from the wave's token scratch (strip_span)
+        if (STRIPQ) {  // the span's next tokens, straight from the wave's token scratch (asked for when v was known)
+#if !PZG_STRIP_PREFETCH
             strip_consume(v);
             strip_refill();
+#endif
+            strip_take();
             return ST_OK;
         }
         // the queue moves up by v tokens
@@ -2044,9 +2080,13 @@ struct Decoder {
 #ifndef PZG_STRIP_BACK
 #define PZG_STRIP_BACK 768
 #endif
+#ifndef PZG_STRIP_PREFETCH
+#define PZG_STRIP_PREFETCH 1
+#endif
     static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may store per span (a multiple of 4)
     static constexpr uint32_t STRIP_RSTRIDE = STRIP_TMAX + 4u;  // a region: 4 words of slack (the last, partial group of four is stored
                                                                 // as the lane's last four tokens, which may reach below the region), then the tokens
+    static constexpr uint32_t STRIP_SPARE = 64u * STRIP_RSTRIDE + 64u;   // a line nobody reads
     static constexpr uint32_t STRIP_WORDS = 64u * STRIP_RSTRIDE + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
     static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits
     static constexpr uint32_t STRIP_CMIN = 256u;                // shorter strips are not worth a span
@@ -2069,7 +2109,9 @@ struct Decoder {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
-    // the queue = the next tokens of the span: the rest of region s_reg from s_idx on, then region s_reg + 1
+    // the queue-to-be (QTN, s_qn) = the next tokens of the span: the rest of region s_reg from s_idx on, then region s_reg + 1.
+    // Asked for as soon as a segment knows how many tokens it takes, taken over when the segment is done (strip_take): the
+    // load's latency passes behind the segment's own work.
     PZG_FN void strip_refill()
     {
         uint32_t n0 = lane_get(SCNT, s_reg) - s_idx;
@@ -2081,10 +2123,15 @@ struct Decoder {
         const uint32_t n1 = s_reg < s_last ? lane_get(SCNT, s_reg + 1u) : 0u;
         const uint32_t a0 = strip_region(s_reg) + s_idx, a1 = strip_region(s_reg + 1u) - n0;
         PZG_LANES_BEGIN(j)
-            PZG_LV(QT, j) = strip_load((j < n0 ? a0 : a1) + j);  // (past both regions: some word of the scratch, never looked at)
+            PZG_LV(QTN, j) = strip_load((j < n0 ? a0 : a1) + j);  // (past both regions: some word of the scratch, never looked at)
         PZG_LANES_END
         const uint32_t left = n0 + n1;
-        qn = left < QCAP ? left : QCAP;
+        s_qn = left < QCAP ? left : QCAP;
+    }
+    PZG_FN void strip_take()
+    {
+        QT = QTN;
+        qn = s_qn;
     }
     PZG_FN void strip_consume(uint32_t v)
     {
@@ -2113,15 +2160,63 @@ struct Decoder {
     // bit 0 (below 64 between steps), nx = the next pair of dwords to fetch.  A token is at most 48 bits: r + 48 <= 112, so b0..b3
     // hold it; b4, b5 are the fetch in flight.  (Pairs past `maxdw` -- the stream's last dwords -- repeat that pair: no token
     // of a span reaches there.)
+    // (round 4, measured: written as an ordinary load inside a lane-dependent branch, the fetch goes to a temporary register
+    // that is copied into place at once -- a wait for HBM in every step.  So the fetch is straight-line code: every step
+    // every lane loads a pair -- the lanes that move on their next one, the others the span's first, one cache line for all --
+    // into a landing register of the STEP (TA in even steps, TB in odd ones), and the pair is put in its place two steps
+    // later, at the top of the step that reuses the landing register: by then it has arrived.  A lane's two pairs in flight go
+    // to two slots, pair j to slot j & 1, and a shift takes the older one -- asked for at the lane's last shift but one, two
+    // steps ago or earlier, so it is always in its slot when it is wanted.)
     struct StripReader {
-        LaneVec<uint32_t> B0, B1, B2, B3, B4, B5, R, NX;
+        LaneVec<uint64_t> W0, W1, L0, L1;  // dwords (b0, b1), (b2, b3); the slots of the next two pairs
+        LaneVec<uint64_t> TA, TB;           // the landing registers
+        LaneVec<uint32_t> PA, PB;           // ... 0: nothing for this lane, 1 / 2: for slot 0 / 1
+        LaneVec<uint32_t> R, NX;
     };
-    PZG_FN static uint32_t strip_dw(const uint32_t *sp, uint32_t i) { return sp[i]; }
+    PZG_FN static uint64_t strip_pair(const uint32_t *sp, uint32_t i)
+    {
+        const uint32_t *q = (const uint32_t *)(const void *)((const uint8_t *)(const void *)sp + (i << 2));
+        return (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+    }
+    // position a lane's reader at bit p of the span
+    PZG_FN static void strip_open(const uint32_t *sp, uint32_t maxdw, uint32_t p, uint64_t &w0, uint64_t &w1, uint64_t &l0, uint64_t &l1,
+                                  uint32_t &r, uint32_t &nx)
+    {
+        const uint32_t g2 = (p >> 6) << 1;
+        w0 = strip_pair(sp, g2 < maxdw ? g2 : maxdw);
+        w1 = strip_pair(sp, g2 + 2u < maxdw ? g2 + 2u : maxdw);
+        const uint64_t a = strip_pair(sp, g2 + 4u < maxdw ? g2 + 4u : maxdw), b = strip_pair(sp, g2 + 6u < maxdw ? g2 + 6u : maxdw);
+        const bool odd = (g2 & 2u) != 0u;  // (pair j = dwords 2j, 2j + 1 belongs in slot j & 1)
+        l0 = odd ? b : a;
+        l1 = odd ? a : b;
+        r = p & 63u;
+        nx = g2 + 8u;
+    }
+    // the pair that landed goes to its slot
+    PZG_FN static void strip_merge(uint64_t t, uint32_t pend, uint64_t &l0, uint64_t &l1)
+    {
+        l0 = pend == 1u ? t : l0;
+        l1 = pend == 2u ? t : l1;
+    }
+    // after a token: 64 bits on if the position says so -- the pairs move down, the next one is asked for
+    PZG_FN static void strip_advance(const uint32_t *sp, uint32_t maxdw, uint64_t &w0, uint64_t &w1, const uint64_t &l0, const uint64_t &l1,
+                                     uint32_t &r, uint32_t &nx, uint64_t &t, uint32_t &pend)
+    {
+        const bool sh = r >= 64u, odd = (nx & 2u) != 0u;
+        const uint64_t older = odd ? l1 : l0;
+        w0 = sh ? w1 : w0;
+        w1 = sh ? older : w1;
+        t = strip_pair(sp, sh ? (nx < maxdw ? nx : maxdw) : 0u);
+        pend = sh ? (odd ? 2u : 1u) : 0u;
+        nx += sh ? 2u : 0u;
+        r -= sh ? 64u : 0u;
+    }
 #define PZG_SR(f) PZG_LV(rd.f, k)
     // one lane's token at its position: tb = its bits (>= 128: a stopper), tk = the token
     template <bool FX>
-    PZG_FN void strip_token(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t r, bool lsub, bool dsub, uint32_t &tb, uint32_t &tk)
+    PZG_FN void strip_token(uint64_t w0, uint64_t w1, uint32_t r, bool lsub, bool dsub, uint32_t &tb, uint32_t &tk)
     {
+        const uint32_t b0 = (uint32_t)w0, b1 = (uint32_t)(w0 >> 32), b2 = (uint32_t)w1, b3 = (uint32_t)(w1 >> 32);
         const bool up = r >= 32u;
         Spec t;
         spec_bits<FX>(t, up ? b1 : b0, up ? b2 : b1, up ? b3 : b2, r);  // (the funnel shifts take r modulo 32)
@@ -2129,6 +2224,76 @@ struct Decoder {
         spec_dist<FX>(t);
         if (!FX && dsub) spec_dsub(t);
         spec_finish(t, tb, tk);
+    }
+    // One step of phase A for every lane still in its run-up; false: none is.  (T, PD: this step's landing register.)
+    template <bool FX>
+    PZG_FN bool strip_step_a(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, StripReader &rd, LaneVec<uint32_t> &P,
+                             const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
+    {
+        LaneVec<bool> ACT;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(ACT, k) = PZG_LV(P, k) < PZG_LV(LIM, k);
+        PZG_LANES_END
+        if (lanes_ballot(ACT) == 0ull) return false;
+        PZG_LANES_BEGIN(k)
+            strip_merge(PZG_LV(T, k), PZG_LV(PD, k), PZG_SR(L0), PZG_SR(L1));
+            uint32_t tb, tk;
+            strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk);
+            const uint32_t adv = PZG_LV(ACT, k) ? (tb < 128u ? tb : 1u) : 0u;  // (no token here: this is not the chain yet)
+            PZG_LV(P, k) += adv;
+            PZG_SR(R) += adv;
+            strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
+        PZG_LANES_END
+        PZG_STAT(16, 1);  // steps of phase A
+        return true;
+    }
+    struct StripOut {
+        LaneVec<uint32_t> N, STF, T0, T1, T2, T3;  // tokens stored; 1 = met a stopper, 2 = region full; the last four tokens
+    };
+    // ... of phase B, for the lanes of `dirty` that have not reached the end of their strip
+    template <bool FX>
+    PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd, StripOut &o,
+                             LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
+    {
+        LaneVec<bool> ACT;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(ACT, k) = lane_bit(dirty, k) & (PZG_LV(o.STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k));
+        PZG_LANES_END
+        if (lanes_ballot(ACT) == 0ull) return false;
+        PZG_LANES_BEGIN(k)
+            strip_merge(PZG_LV(T, k), PZG_LV(PD, k), PZG_SR(L0), PZG_SR(L1));
+            uint32_t tb, tk;
+            strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk);
+            const bool act = PZG_LV(ACT, k), full = PZG_LV(o.N, k) >= STRIP_TMAX, stop = tb >= 128u;
+            const bool ok = act & !stop & !full;
+            PZG_LV(o.STF, k) = (act & stop) ? 1u : (act & full) ? 2u : PZG_LV(o.STF, k);
+            PZG_LV(o.T0, k) = ok ? PZG_LV(o.T1, k) : PZG_LV(o.T0, k);
+            PZG_LV(o.T1, k) = ok ? PZG_LV(o.T2, k) : PZG_LV(o.T1, k);
+            PZG_LV(o.T2, k) = ok ? PZG_LV(o.T3, k) : PZG_LV(o.T2, k);
+            PZG_LV(o.T3, k) = ok ? tk : PZG_LV(o.T3, k);
+            PZG_LV(o.N, k) += ok ? 1u : 0u;
+            const uint32_t adv = ok ? tb : 0u;
+            PZG_LV(P, k) += adv;
+            PZG_SR(R) += adv;
+            {  // four more tokens: one 16-byte store (straight-line like the fetch -- the lanes with nothing to store write to one
+               // spare line of the scratch -- so that the compiler can count what is in flight)
+                const bool grp = ok & ((PZG_LV(o.N, k) & 3u) == 0u);
+                uint32_t *q = strip + (grp ? strip_region(k) + PZG_LV(o.N, k) - 4u : STRIP_SPARE);
+                q[0] = PZG_LV(o.T0, k); q[1] = PZG_LV(o.T1, k); q[2] = PZG_LV(o.T2, k); q[3] = PZG_LV(o.T3, k);
+            }
+            strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
+        PZG_LANES_END
+        PZG_STAT(17, 1);  // steps of phase B
+        return true;
+    }
+    PZG_FN void strip_drain(StripReader &rd)  // what is still landing goes to its slot
+    {
+        PZG_LANES_BEGIN(k)
+            strip_merge(PZG_SR(TA), PZG_SR(PA), PZG_SR(L0), PZG_SR(L1));
+            strip_merge(PZG_SR(TB), PZG_SR(PB), PZG_SR(L0), PZG_SR(L1));
+            PZG_SR(PA) = 0u;
+            PZG_SR(PB) = 0u;
+        PZG_LANES_END
     }
 
     // Decodes and emits one span.  STRIP_NA: nothing done (too little input ahead; the windows take over);
@@ -2169,46 +2334,25 @@ struct Decoder {
             PZG_LV(LIM, k) = r0 + lo;
             const uint32_t p = r0 + (lo > STRIP_BACK ? lo - STRIP_BACK : 0u);  // (from the cursor itself: exact)
             PZG_LV(P, k) = p;
-            const uint32_t g2 = (p >> 6) << 1;
-            const uint32_t i0 = g2 < maxdw ? g2 : maxdw, i1 = g2 + 2u < maxdw ? g2 + 2u : maxdw, i2 = g2 + 4u < maxdw ? g2 + 4u : maxdw;
-            PZG_SR(B0) = sp[i0]; PZG_SR(B1) = sp[i0 + 1u];
-            PZG_SR(B2) = sp[i1]; PZG_SR(B3) = sp[i1 + 1u];
-            PZG_SR(B4) = sp[i2]; PZG_SR(B5) = sp[i2 + 1u];
-            PZG_SR(R) = p & 63u;
-            PZG_SR(NX) = g2 + 6u;
+            strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
+            PZG_SR(TA) = PZG_SR(TB) = 0ull;
+            PZG_SR(PA) = PZG_SR(PB) = 0u;
         PZG_LANES_END
         for (;;) {
-            LaneVec<bool> ACT;
-            PZG_LANES_BEGIN(k)
-                PZG_LV(ACT, k) = PZG_LV(P, k) < PZG_LV(LIM, k);
-            PZG_LANES_END
-            if (lanes_ballot(ACT) == 0ull) break;
-            PZG_LANES_BEGIN(k)
-                uint32_t tb, tk;
-                strip_token<FX>(PZG_SR(B0), PZG_SR(B1), PZG_SR(B2), PZG_SR(B3), PZG_SR(R), lsub, dsub, tb, tk);
-                const uint32_t adv = PZG_LV(ACT, k) ? (tb < 128u ? tb : 1u) : 0u;  // (no token here: this is not the chain yet)
-                PZG_LV(P, k) += adv;
-                PZG_SR(R) += adv;
-                if (PZG_SR(R) >= 64u) {
-                    const uint32_t i = PZG_SR(NX) < maxdw ? PZG_SR(NX) : maxdw;
-                    PZG_SR(B0) = PZG_SR(B2); PZG_SR(B1) = PZG_SR(B3); PZG_SR(B2) = PZG_SR(B4); PZG_SR(B3) = PZG_SR(B5);
-                    PZG_SR(B4) = sp[i]; PZG_SR(B5) = sp[i + 1u];
-                    PZG_SR(NX) += 2u;
-                    PZG_SR(R) -= 64u;
-                }
-            PZG_LANES_END
-            PZG_STAT(16, 1);  // steps of phase A
+            if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TA, rd.PA)) break;
+            if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TB, rd.PB)) break;
         }
+        strip_drain(rd);
         // phase B: the strips, until every lane started where its neighbour ended
         PZG_HOT_ACC(8, tsa);
         PZG_T0(tsb);
-        LaneVec<uint32_t> N, STF, T0, T1, T2, T3;  // tokens stored; 1 = met a stopper, 2 = region full; the last four tokens
+        StripOut o;
         PZG_LANES_BEGIN(k)
             PZG_LV(S, k) = PZG_LV(P, k);
             PZG_LV(LIM, k) += C;
-            PZG_LV(N, k) = 0u;
-            PZG_LV(STF, k) = 0u;
-            PZG_LV(T0, k) = PZG_LV(T1, k) = PZG_LV(T2, k) = PZG_LV(T3, k) = 0u;
+            PZG_LV(o.N, k) = 0u;
+            PZG_LV(o.STF, k) = 0u;
+            PZG_LV(o.T0, k) = PZG_LV(o.T1, k) = PZG_LV(o.T2, k) = PZG_LV(o.T3, k) = 0u;
         PZG_LANES_END
         uint64_t dirty = ~0ull, stopm = 0ull;
         uint32_t last = 63u;
@@ -2218,57 +2362,22 @@ struct Decoder {
                     if (lane_bit(dirty, k)) {
                         const uint32_t p = PZG_LV(S, k);
                         PZG_LV(P, k) = p;
-                        PZG_LV(N, k) = 0u;
-                        PZG_LV(STF, k) = 0u;
-                        const uint32_t g2 = (p >> 6) << 1;
-                        const uint32_t i0 = g2 < maxdw ? g2 : maxdw, i1 = g2 + 2u < maxdw ? g2 + 2u : maxdw, i2 = g2 + 4u < maxdw ? g2 + 4u : maxdw;
-                        PZG_SR(B0) = sp[i0]; PZG_SR(B1) = sp[i0 + 1u];
-                        PZG_SR(B2) = sp[i1]; PZG_SR(B3) = sp[i1 + 1u];
-                        PZG_SR(B4) = sp[i2]; PZG_SR(B5) = sp[i2 + 1u];
-                        PZG_SR(R) = p & 63u;
-                        PZG_SR(NX) = g2 + 6u;
+                        PZG_LV(o.N, k) = 0u;
+                        PZG_LV(o.STF, k) = 0u;
+                        strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
                     }
                 PZG_LANES_END
             }
             for (;;) {
-                LaneVec<bool> ACT;
-                PZG_LANES_BEGIN(k)
-                    PZG_LV(ACT, k) = lane_bit(dirty, k) & (PZG_LV(STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k));
-                PZG_LANES_END
-                if (lanes_ballot(ACT) == 0ull) break;
-                PZG_LANES_BEGIN(k)
-                    uint32_t tb, tk;
-                    strip_token<FX>(PZG_SR(B0), PZG_SR(B1), PZG_SR(B2), PZG_SR(B3), PZG_SR(R), lsub, dsub, tb, tk);
-                    const bool act = PZG_LV(ACT, k), full = PZG_LV(N, k) >= STRIP_TMAX, stop = tb >= 128u;
-                    const bool ok = act & !stop & !full;
-                    PZG_LV(STF, k) = (act & stop) ? 1u : (act & full) ? 2u : PZG_LV(STF, k);
-                    PZG_LV(T0, k) = ok ? PZG_LV(T1, k) : PZG_LV(T0, k);
-                    PZG_LV(T1, k) = ok ? PZG_LV(T2, k) : PZG_LV(T1, k);
-                    PZG_LV(T2, k) = ok ? PZG_LV(T3, k) : PZG_LV(T2, k);
-                    PZG_LV(T3, k) = ok ? tk : PZG_LV(T3, k);
-                    PZG_LV(N, k) += ok ? 1u : 0u;
-                    const uint32_t adv = ok ? tb : 0u;
-                    PZG_LV(P, k) += adv;
-                    PZG_SR(R) += adv;
-                    if (ok & ((PZG_LV(N, k) & 3u) == 0u)) {  // four more tokens: one 16-byte store
-                        uint32_t *q = strip + strip_region(k) + PZG_LV(N, k) - 4u;
-                        q[0] = PZG_LV(T0, k); q[1] = PZG_LV(T1, k); q[2] = PZG_LV(T2, k); q[3] = PZG_LV(T3, k);
-                    }
-                    if (PZG_SR(R) >= 64u) {
-                        const uint32_t i = PZG_SR(NX) < maxdw ? PZG_SR(NX) : maxdw;
-                        PZG_SR(B0) = PZG_SR(B2); PZG_SR(B1) = PZG_SR(B3); PZG_SR(B2) = PZG_SR(B4); PZG_SR(B3) = PZG_SR(B5);
-                        PZG_SR(B4) = sp[i]; PZG_SR(B5) = sp[i + 1u];
-                        PZG_SR(NX) += 2u;
-                        PZG_SR(R) -= 64u;
-                    }
-                PZG_LANES_END
-                PZG_STAT(17, 1);  // steps of phase B
+                if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM, rd.TA, rd.PA)) break;
+                if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM, rd.TB, rd.PB)) break;
             }
+            strip_drain(rd);
             // the last, partial group of every lane that ran: its last four tokens, wherever they end
             PZG_LANES_BEGIN(k)
                 if (lane_bit(dirty, k)) {
-                    uint32_t *q = strip + strip_region(k) + PZG_LV(N, k) - 4u;
-                    q[0] = PZG_LV(T0, k); q[1] = PZG_LV(T1, k); q[2] = PZG_LV(T2, k); q[3] = PZG_LV(T3, k);
+                    uint32_t *q = strip + strip_region(k) + PZG_LV(o.N, k) - 4u;
+                    q[0] = PZG_LV(o.T0, k); q[1] = PZG_LV(o.T1, k); q[2] = PZG_LV(o.T2, k); q[3] = PZG_LV(o.T3, k);
                 }
             PZG_LANES_END
             // lane k must have started where lane k - 1's chain left its strip; lanes behind the first one that stopped do not count
@@ -2276,7 +2385,7 @@ struct Decoder {
             LaneVec<bool> BAD, STOPPED;
             PZG_LANES_BEGIN(k)
                 PZG_LV(PREV, k) = k - 1u;
-                PZG_LV(STOPPED, k) = PZG_LV(STF, k) != 0u;
+                PZG_LV(STOPPED, k) = PZG_LV(o.STF, k) != 0u;
             PZG_LANES_END
             lanes_gather(NS, P, PREV);
             stopm = lanes_ballot(STOPPED);
@@ -2295,12 +2404,12 @@ struct Decoder {
             last = ctz64(dirty) - 1u;
             stopm = 0ull;
         }
-        stopper = stopm != 0ull && lane_get(STF, last) == 1u;
+        stopper = stopm != 0ull && lane_get(o.STF, last) == 1u;
         const uint32_t pend = lane_get(P, last);
         PZG_HOT_ACC(9, tsb);
         PZG_T0(tsc);
         PZG_LANES_BEGIN(k)
-            PZG_LV(SCNT, k) = k <= last ? PZG_LV(N, k) : 0u;
+            PZG_LV(SCNT, k) = k <= last ? PZG_LV(o.N, k) : 0u;
         PZG_LANES_END
         s_reg = 0u;
         s_idx = 0u;
@@ -2322,6 +2431,7 @@ struct Decoder {
         br.drop((uint32_t)endbit & 7u);
         strip_fence();
         strip_refill();
+        strip_take();
         PZG_HOT_ACC(10, tsc);
         PZG_T0(tse);
         // segments for as long as tokens are left (the fast body in a loop of its own: see hot_loop())
@@ -2684,7 +2794,7 @@ struct Decoder {
         use_sub = 0;
         lit_sub_used = 0;
         dist_sub_used = 0;
-        s_reg = s_idx = s_last = 0;
+        s_reg = s_idx = s_last = s_qn = 0;
         pend_m0 = pend_m1 = 0;
         pend_pos = 0;
         qn = 0;

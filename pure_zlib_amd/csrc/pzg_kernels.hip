@@ -23,11 +23,11 @@ namespace pzg {
 #ifndef PZG_MIN_WAVES_11
 #define PZG_MIN_WAVES_11 7
 #endif
-// (the gzip instance of ring 11 needs a few more vector registers than the zlib one: 80, six waves per SIMD, 24 stream-waves
-// per CU instead of 26 -- and nothing in scratch, which round 2's 72-register build of it had)
+// (the gzip instance of ring 11 needs more vector registers than the zlib one: five waves per SIMD, 20 stream-waves per CU
+// instead of 26 -- with the strips the kernels' speed levels off at ~20 per CU anyway -- and nothing in scratch)
 constexpr int waves_per_simd(int ring_bits, bool gzip = false)
 {
-    return ring_bits <= 11 ? (gzip ? 6 : PZG_MIN_WAVES_11) : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
+    return ring_bits <= 11 ? (gzip ? 5 : PZG_MIN_WAVES_11) : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
 }
 template <int RING_BITS, bool GZIP = false>
 constexpr uint32_t waves_per_cu()

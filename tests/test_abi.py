@@ -67,8 +67,9 @@ def test_ring11_kernels_use_no_scratch():
         if "inflate_kernelILi1" in name:  # every ring size class, zlib and gzip, and the fixup instances
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
     for name, k in ring11.items():
-        assert k["sgpr_spill_count"] <= 128, (name, k["sgpr_spill_count"])
-        assert k["vgpr_count"] <= (80 if "Lb0ELb1E" in name else 72), (name, k["vgpr_count"])  # gzip 6, zlib 7 waves per SIMD by registers
+        # (round 4: strip_span() keeps ~30 more wave-uniform values alive beside the decoder's state -- 128 -> 256)
+        assert k["sgpr_spill_count"] <= 256, (name, k["sgpr_spill_count"])
+        assert k["vgpr_count"] <= (96 if "Lb0ELb1E" in name else 72), (name, k["vgpr_count"])  # gzip 5, zlib 7 waves per SIMD by registers
         assert k["group_segment_fixed_size"] <= 6144, name  # 26 stream-waves per CU
 
 
