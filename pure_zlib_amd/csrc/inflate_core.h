@@ -2084,15 +2084,18 @@ struct Decoder {
 #define PZG_STRIP_PREFETCH 1
 #endif
     static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may store per span (a multiple of 4)
-    static constexpr uint32_t STRIP_RSTRIDE = STRIP_TMAX + 4u;  // a region: 4 words of slack (the last, partial group of four is stored
-                                                                // as the lane's last four tokens, which may reach below the region), then the tokens
-    static constexpr uint32_t STRIP_SPARE = 64u * STRIP_RSTRIDE + 64u;   // a line nobody reads
+#ifndef PZG_STRIP_GROUP
+#define PZG_STRIP_GROUP 8
+#endif
+    static constexpr uint32_t STRIP_GROUP = PZG_STRIP_GROUP;    // tokens per store (4 or 8)
+    static constexpr uint32_t STRIP_RSTRIDE = STRIP_TMAX + STRIP_GROUP;  // a region: a group of slack (the last, partial group is stored
+                                                                // as the lane's last tokens, which may reach below the region), then the tokens
     static constexpr uint32_t STRIP_WORDS = 64u * STRIP_RSTRIDE + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
     static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits
     static constexpr uint32_t STRIP_CMIN = 256u;                // shorter strips are not worth a span
     static constexpr uint32_t STRIP_ROUNDS = 6u;
     static constexpr int STRIP_NA = -2;
-    PZG_FN static constexpr uint32_t strip_region(uint32_t k) { return k * STRIP_RSTRIDE + 4u; }
+    PZG_FN static constexpr uint32_t strip_region(uint32_t k) { return k * STRIP_RSTRIDE + STRIP_GROUP; }
 
     // the wave's own stores of a moment ago, read back by OTHER lanes: device-scope loads (not served from a stale L1 line)
     PZG_FN uint32_t strip_load(uint32_t i) const
@@ -2248,8 +2251,15 @@ struct Decoder {
         return true;
     }
     struct StripOut {
-        LaneVec<uint32_t> N, STF, T0, T1, T2, T3;  // tokens stored; 1 = met a stopper, 2 = region full; the last four tokens
+        LaneVec<uint32_t> N, STF;        // tokens stored; 1 = met a stopper, 2 = region full
+        LaneVec<uint32_t> T[STRIP_GROUP];  // the last tokens, T[STRIP_GROUP - 1] the newest
     };
+    PZG_FN void strip_store_group(const StripOut &o, uint32_t k, uint32_t at)
+    {
+        uint32_t *q = strip + at;
+#pragma unroll
+        for (uint32_t g = 0; g < STRIP_GROUP; ++g) q[g] = PZG_LV(o.T[g], k);
+    }
     // ... of phase B, for the lanes of `dirty` that have not reached the end of their strip
     template <bool FX>
     PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd, StripOut &o,
@@ -2267,19 +2277,19 @@ struct Decoder {
             const bool act = PZG_LV(ACT, k), full = PZG_LV(o.N, k) >= STRIP_TMAX, stop = tb >= 128u;
             const bool ok = act & !stop & !full;
             PZG_LV(o.STF, k) = (act & stop) ? 1u : (act & full) ? 2u : PZG_LV(o.STF, k);
-            PZG_LV(o.T0, k) = ok ? PZG_LV(o.T1, k) : PZG_LV(o.T0, k);
-            PZG_LV(o.T1, k) = ok ? PZG_LV(o.T2, k) : PZG_LV(o.T1, k);
-            PZG_LV(o.T2, k) = ok ? PZG_LV(o.T3, k) : PZG_LV(o.T2, k);
-            PZG_LV(o.T3, k) = ok ? tk : PZG_LV(o.T3, k);
+#pragma unroll
+            for (uint32_t g = 0; g + 1u < STRIP_GROUP; ++g) PZG_LV(o.T[g], k) = ok ? PZG_LV(o.T[g + 1u], k) : PZG_LV(o.T[g], k);
+            PZG_LV(o.T[STRIP_GROUP - 1u], k) = ok ? tk : PZG_LV(o.T[STRIP_GROUP - 1u], k);
             PZG_LV(o.N, k) += ok ? 1u : 0u;
             const uint32_t adv = ok ? tb : 0u;
             PZG_LV(P, k) += adv;
             PZG_SR(R) += adv;
-            {  // four more tokens: one 16-byte store (straight-line like the fetch -- the lanes with nothing to store write to one
-               // spare line of the scratch -- so that the compiler can count what is in flight)
-                const bool grp = ok & ((PZG_LV(o.N, k) & 3u) == 0u);
-                uint32_t *q = strip + (grp ? strip_region(k) + PZG_LV(o.N, k) - 4u : STRIP_SPARE);
-                q[0] = PZG_LV(o.T0, k); q[1] = PZG_LV(o.T1, k); q[2] = PZG_LV(o.T2, k); q[3] = PZG_LV(o.T3, k);
+            {  // a full group of tokens: one aligned store per lane that has one.  (Measured, text / literal-heavy data: groups of 4 / 8 /
+               // 16 tokens 217 / 234 / 237 and 93 / 113 / 120 GiB/s -- the scratch is written in pieces of lines, and the fewer
+               // and larger the pieces the less of it is written twice; every lane's last four tokens every fourth step, wherever
+               // they end -- a quarter of the store instructions, but unaligned and overlapping -- cost text 20 %.)
+                const bool grp = ok & ((PZG_LV(o.N, k) & (STRIP_GROUP - 1u)) == 0u);
+                if (grp) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - STRIP_GROUP);
             }
             strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
         PZG_LANES_END
@@ -2352,7 +2362,8 @@ struct Decoder {
             PZG_LV(LIM, k) += C;
             PZG_LV(o.N, k) = 0u;
             PZG_LV(o.STF, k) = 0u;
-            PZG_LV(o.T0, k) = PZG_LV(o.T1, k) = PZG_LV(o.T2, k) = PZG_LV(o.T3, k) = 0u;
+#pragma unroll
+            for (uint32_t g = 0; g < STRIP_GROUP; ++g) PZG_LV(o.T[g], k) = 0u;
         PZG_LANES_END
         uint64_t dirty = ~0ull, stopm = 0ull;
         uint32_t last = 63u;
@@ -2375,10 +2386,7 @@ struct Decoder {
             strip_drain(rd);
             // the last, partial group of every lane that ran: its last four tokens, wherever they end
             PZG_LANES_BEGIN(k)
-                if (lane_bit(dirty, k)) {
-                    uint32_t *q = strip + strip_region(k) + PZG_LV(o.N, k) - 4u;
-                    q[0] = PZG_LV(o.T0, k); q[1] = PZG_LV(o.T1, k); q[2] = PZG_LV(o.T2, k); q[3] = PZG_LV(o.T3, k);
-                }
+                if (lane_bit(dirty, k)) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - STRIP_GROUP);
             PZG_LANES_END
             // lane k must have started where lane k - 1's chain left its strip; lanes behind the first one that stopped do not count
             LaneVec<uint32_t> NS, PREV;
