@@ -513,7 +513,6 @@ struct Decoder {
     uint8_t *hist;
     const uint8_t *far_base;    // far reads: far_base + 32768 is produced-byte `flushed` (or the input, see set_far_base)
     uint64_t far_okmask;        // all ones while far reads may touch the output (128 <= flushed < cap), else 0
-    uint32_t fence_due;         // flush stores may still be on their way: the next far read waits for them (far_fence)
     // What a lane with no far source reads (the far load is unconditional: see segment_store): a byte one whole cache
     // line or more below `flushed` -- or the stream's first input byte while nothing may be read from the output.
     static constexpr uint32_t FAR_IDLE = 32768u - 128u;
@@ -573,7 +572,6 @@ struct Decoder {
         pend_pos = uni(pend_pos);
         hist_extra = uni(hist_extra);
         far_okmask = uni64(far_okmask);
-        fence_due = uni(fence_due);
         qn = uni(qn);
         in_byte0 = uni64(in_byte0);
         status = (int32_t)uni((uint32_t)status);
@@ -761,7 +759,6 @@ struct Decoder {
         const bool ok = flushed < cap && flushed >= 128u;  // (below 2 KiB of output nothing is far anyway)
         far_base = ok ? out + (flushed - 32768u) : in - FAR_IDLE;
         far_okmask = ok ? ~0ull : 0ull;
-        fence_due = 1u;  // (called after every flush)
     }
 
     // store the last segment's far bytes (see pend_m0), then flush if due: from here on every byte below `op` is in the ring
@@ -827,17 +824,10 @@ struct Decoder {
     PZG_FN uint8_t fetch_near(uint32_t back) const { return L.ring[((uint32_t)op - back) & RMASK]; }
     // Before far reads: every flush store of this wave must have landed.  By the time a byte is older
     // than the ring its flush is long complete, so this wait is normally free.
-    // (Only the first far read after a flush has anything to wait for: with the strips' token loads in flight an unconditional
-    // wait would stall every segment that has a far byte.)
-    PZG_FN void far_fence()
+    PZG_FN void far_fence() const
     {
 #if PZG_DEVICE_PASS
-        if (RES) {  // (the resumable instance, at the limit of its registers, keeps the plain wait)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (fence_due) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fence_due = 0u;
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
     PZG_FN uint8_t fetch_far(bool is_far, uint32_t back) const
@@ -1792,11 +1782,10 @@ struct Decoder {
         PZG_T0(t_a);
         // the previous segment's bytes must all be in the ring from here on
         if (FAST) {
-            // (the far bytes of the last segment are waited for as late as possible -- in front of this segment's first ring read:
-            // the scan below needs none of them; the resumable instance, at the limit of its registers, keeps the old order)
-            if (RES) pending_stores();
+            // (tried with the strips: waiting for the last segment's far bytes only in front of this segment's first ring read, and
+            // a far fence only after a flush -- nothing for the strips, and the windows' loop lost 20 % to the changed code)
+            pending_stores();
             if (__builtin_expect((uint32_t)(op - flushed) >= FLUSH_AT, 0)) {  // whole KiB only (the general flush goes up to op & ~15)
-                pending_stores();
                 const uint64_t to = flushed + ((uint32_t)(op - flushed) & ~1023u);
                 if (!out_aligned() || to > cap) return EMIT_BAIL;
                 flush_span<true>(to);
@@ -1882,7 +1871,6 @@ struct Decoder {
             PZG_STAT(8, run);   // bytes of non-degenerate segments
             PZG_STAT(9, v);     // their tokens
             PZG_STAT(10, run > 64u ? 1 : 0);
-            if (FAST && !RES) pending_stores();
             if (run == v) {
                 // one byte per token: nothing but literals (a match is three bytes or more).  Byte j IS token j's byte:
                 // no announcements, no gathers -- literal-heavy data (little or no redundancy) spends its time here.
@@ -2092,7 +2080,10 @@ struct Decoder {
                                                                 // as the lane's last tokens, which may reach below the region), then the tokens
     static constexpr uint32_t STRIP_WORDS = 64u * STRIP_RSTRIDE + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
     static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits
-    static constexpr uint32_t STRIP_CMIN = 256u;                // shorter strips are not worth a span
+#ifndef PZG_STRIP_CMIN
+#define PZG_STRIP_CMIN 256
+#endif
+    static constexpr uint32_t STRIP_CMIN = PZG_STRIP_CMIN;      // shorter strips are not worth a span
     static constexpr uint32_t STRIP_ROUNDS = 6u;
     static constexpr int STRIP_NA = -2;
     PZG_FN static constexpr uint32_t strip_region(uint32_t k) { return k * STRIP_RSTRIDE + STRIP_GROUP; }

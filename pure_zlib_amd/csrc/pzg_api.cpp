@@ -336,6 +336,9 @@ int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
     if (sh.strip_used[ss]) HIP_TRY(ctx, hipStreamWaitEvent(sh.stream, sh.ev_strip[ss], 0));
     if (arena_reserve(ctx, sh.a_strip[ss], pzg::inflate_strip_bytes(ctx->ring_bits, sh.num_cus, a.n, a.gzip)) == PZG_RC_OK)
         a.strip = (uint32_t *)sh.a_strip[ss].p;
+#if defined(PZG_LAB)  // lab builds only: the windows alone
+    if (getenv("PZG_NO_STRIPS")) a.strip = nullptr;
+#endif
     HIP_TRY(ctx, hipEventRecord(sh.ev0, sh.stream));
     HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, sh.stream));
     HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
