@@ -127,7 +127,11 @@ extern "C" {
 typedef struct pzg_ctx pzg_ctx;
 
 /* Create a context on HIP device `device` (0-based).  One HIP stream + grow-only device
- * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device. */
+ * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device.
+ * Device memory the library takes for itself, grow-only until pzg_shutdown: the kernels' token scratch -- 34.5 KiB per stream-wave
+ * of a launch (one wave per stream, at most the residency of the chip: 6,656 waves = 224 MiB on an MI355X), two such arenas per
+ * device for PZG_DEVICE_PTRS launches and one per host-path pipeline in use -- beside the host path's staging arenas.  A launch
+ * whose scratch cannot be allocated still decodes, by the slower window path alone. */
 PZG_API int  pzg_init(int device, pzg_ctx **out);
 /* decompressMany over SEVERAL devices of one node (API of Zlib.hs:32-35, batched): bit d of `device_mask`
  * selects HIP device d, 0 selects every visible device.  One call of pzg_decompress_many() with HOST pointers then
