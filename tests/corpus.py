@@ -181,3 +181,29 @@ def splitmix64_torch(first, count, dev):
     z = (z ^ lsr(z, 30)) * i64(0xBF58476D1CE4E5B9)
     z = (z ^ lsr(z, 27)) * i64(0x94D049BB133111EB)
     return z ^ lsr(z, 31)
+
+
+def strip_case(seed: int):
+    """(data, stream) long enough for the kernels' strips (spans of 64 x 256 input bits or more): text, html, literal-heavy
+    bytes, four-symbol data (two-bit codes: the shortest strips), pieces of all of them in one stream; one block or many
+    (seeded flush points, fixed / Huffman-only / RLE strategies, stored blocks at level 0)."""
+    rng = random.Random(90000 + seed)
+    n = rng.choice([24000, 40000, 70000, 150000])
+    kind = seed % 6
+    if kind == 0:
+        d = zipf_text(n, seed)
+    elif kind == 1:
+        d = html_slice(min(n, 60000), seed)
+    elif kind == 2:
+        d = skewed_bytes(n, seed)
+    elif kind == 3:
+        d = bytes(rng.choice(b"acgt") for _ in range(n))
+    elif kind == 4:
+        d = zipf_text(n // 3, seed) + skewed_bytes(n // 3, seed) + bytes([seed % 251]) * 5000 + zipf_text(n // 3, seed + 1)
+    else:
+        d = mixed_data(n, seed)
+    if seed % 3 == 0:
+        z = zlib.compress(d, 1 + seed % 9)
+    else:
+        z = compress_variant(d, seed)
+    return d, z

@@ -117,6 +117,36 @@ def test_corrupt_streams_vs_oracle(ctx, oracle):
             assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())
 
 
+def test_strips_valid_and_corrupt_vs_oracle(ctx, oracle):
+    """Round 4: long runs of input are decoded by strips (inflate_core.h strip_span(): 64 lanes, one piece of the input each,
+    speculative starts verified and repaired, tokens through the wave's scratch).  Streams of several spans -- one block and
+    many, every strategy, two-bit codes -- and six corrupted variants of each, in ONE launch (the waves' scratch is reused from
+    stream to stream), against the oracle: status, message, in_used, Adler-32, every byte."""
+    streams, caps, datas = [], [], []
+    for seed in range(48):
+        d, z = corpus.strip_case(seed)
+        streams.append(z)
+        caps.append(len(d))
+        datas.append(d)
+        for c in range(6):
+            streams.append(corpus.corrupt(z, seed * 16 + c))
+            caps.append([len(d) + 64, len(d) // 2][c % 2] if c < 4 else len(d))
+            datas.append(None)
+    (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, caps)
+    import pure_zlib_amd.zlib as Z
+    for k in range(len(streams)):
+        r, o = oracle.decompress(streams[k], caps[k])
+        assert status[k] == r.status, (k, status[k], r.status, r.message.decode())
+        if r.status == 0:
+            assert outs[k] == o and int(adler[k]) == r.adler and int(in_used[k]) == r.in_used and int(out_len[k]) == r.out_len, k
+            assert datas[k] is None or o == datas[k]
+        elif r.status == 14:
+            assert int(out_len[k]) == r.out_len
+        else:
+            err = Z.error_from_status(streams[k], int(status[k]), detail[k])
+            assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())
+
+
 def test_text_blobs_with_far_back_references(ctx, oracle):
     """32-100 KiB Zipf text: distances up to 32 KiB, i.e. older than every hybrid ring."""
     streams, datas = [], []

@@ -127,6 +127,26 @@ def test_model_long_codes_second_level_tables(model, oracle, rb):
             assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
 
 
+@pytest.mark.parametrize("rb,strips", [(11, True), (15, True), (12, True), (11, False)])
+def test_model_strips(model, oracle, rb, strips, monkeypatch):
+    """Round 4: long runs of input are decoded by strips (64 lanes, one piece of the input each, from speculative starts that are
+    verified and repaired; inflate_core.h strip_span()).  Streams long enough for several spans -- one block and many, every
+    strategy, two-bit codes -- and corrupted variants of each against the oracle: status, detail, in_used, every byte.  The
+    same streams once more with the scratch withheld (a launch whose scratch could not be allocated): the windows alone."""
+    if not strips:
+        monkeypatch.setenv("PZM_NO_STRIPS", "1")
+    for seed in range(30 if strips else 12):
+        d, z = corpus.strip_case(seed)
+        r, out = model(z, len(d), rb)
+        assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), seed
+        for c in range(6):
+            zc = corpus.corrupt(z, seed * 16 + c)
+            cap = [len(d) + 64, len(d) // 2][c % 2] if c < 4 else len(d)
+            ro, oo = oracle.decompress(zc, cap)
+            rm, om = model(zc, cap, rb)
+            assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
+
+
 @pytest.mark.parametrize("rb", [15, 14, 11])
 def test_model_gzip_members(model, oracle, rb):
     """The gzip extension (RFC 1952 header / CRC-32 + ISIZE trailer around the same DEFLATE core): the kernel
