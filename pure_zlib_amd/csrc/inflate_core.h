@@ -2073,9 +2073,15 @@ struct Decoder {
 #endif
     static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may store per span (a multiple of 4)
 #ifndef PZG_STRIP_GROUP
-#define PZG_STRIP_GROUP 8
+#define PZG_STRIP_GROUP 16
 #endif
-    static constexpr uint32_t STRIP_GROUP = PZG_STRIP_GROUP;    // tokens per store (4 or 8)
+#ifndef PZG_STRIP_GROUP_FX
+#define PZG_STRIP_GROUP_FX 8
+#endif
+    // tokens per store: 16 in dynamic blocks, 8 in fixed ones (measured: 16 is +1 % on text and +7 % on literal-heavy data over 8,
+    // -1.5 % on the 4 KiB fixed-Huffman batch, whose short strips seldom fill a group of 16)
+    template <bool FX> static constexpr uint32_t strip_group() { return FX ? (uint32_t)PZG_STRIP_GROUP_FX : (uint32_t)PZG_STRIP_GROUP; }
+    static constexpr uint32_t STRIP_GROUP = PZG_STRIP_GROUP > PZG_STRIP_GROUP_FX ? PZG_STRIP_GROUP : PZG_STRIP_GROUP_FX;  // the larger: the regions' slack
     static constexpr uint32_t STRIP_RSTRIDE = STRIP_TMAX + STRIP_GROUP;  // a region: a group of slack (the last, partial group is stored
                                                                 // as the lane's last tokens, which may reach below the region), then the tokens
     static constexpr uint32_t STRIP_WORDS = 64u * STRIP_RSTRIDE + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
@@ -2241,21 +2247,24 @@ struct Decoder {
         PZG_STAT(16, 1);  // steps of phase A
         return true;
     }
+    template <uint32_t G>
     struct StripOut {
-        LaneVec<uint32_t> N, STF;        // tokens stored; 1 = met a stopper, 2 = region full
-        LaneVec<uint32_t> T[STRIP_GROUP];  // the last tokens, T[STRIP_GROUP - 1] the newest
+        LaneVec<uint32_t> N, STF;  // tokens stored; 1 = met a stopper, 2 = region full
+        LaneVec<uint32_t> T[G];    // the last tokens, T[G - 1] the newest
     };
-    PZG_FN void strip_store_group(const StripOut &o, uint32_t k, uint32_t at)
+    template <uint32_t G>
+    PZG_FN void strip_store_group(const StripOut<G> &o, uint32_t k, uint32_t at)
     {
         uint32_t *q = strip + at;
 #pragma unroll
-        for (uint32_t g = 0; g < STRIP_GROUP; ++g) q[g] = PZG_LV(o.T[g], k);
+        for (uint32_t g = 0; g < G; ++g) q[g] = PZG_LV(o.T[g], k);
     }
     // ... of phase B, for the lanes of `dirty` that have not reached the end of their strip
     template <bool FX>
-    PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd, StripOut &o,
-                             LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
+    PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd,
+                             StripOut<strip_group<FX>()> &o, LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
     {
+        constexpr uint32_t G = strip_group<FX>();
         LaneVec<bool> ACT;
         PZG_LANES_BEGIN(k)
             PZG_LV(ACT, k) = lane_bit(dirty, k) & (PZG_LV(o.STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k));
@@ -2269,8 +2278,8 @@ struct Decoder {
             const bool ok = act & !stop & !full;
             PZG_LV(o.STF, k) = (act & stop) ? 1u : (act & full) ? 2u : PZG_LV(o.STF, k);
 #pragma unroll
-            for (uint32_t g = 0; g + 1u < STRIP_GROUP; ++g) PZG_LV(o.T[g], k) = ok ? PZG_LV(o.T[g + 1u], k) : PZG_LV(o.T[g], k);
-            PZG_LV(o.T[STRIP_GROUP - 1u], k) = ok ? tk : PZG_LV(o.T[STRIP_GROUP - 1u], k);
+            for (uint32_t g = 0; g + 1u < G; ++g) PZG_LV(o.T[g], k) = ok ? PZG_LV(o.T[g + 1u], k) : PZG_LV(o.T[g], k);
+            PZG_LV(o.T[G - 1u], k) = ok ? tk : PZG_LV(o.T[G - 1u], k);
             PZG_LV(o.N, k) += ok ? 1u : 0u;
             const uint32_t adv = ok ? tb : 0u;
             PZG_LV(P, k) += adv;
@@ -2279,8 +2288,8 @@ struct Decoder {
                // 16 tokens 217 / 234 / 237 and 93 / 113 / 120 GiB/s -- the scratch is written in pieces of lines, and the fewer
                // and larger the pieces the less of it is written twice; every lane's last four tokens every fourth step, wherever
                // they end -- a quarter of the store instructions, but unaligned and overlapping -- cost text 20 %.)
-                const bool grp = ok & ((PZG_LV(o.N, k) & (STRIP_GROUP - 1u)) == 0u);
-                if (grp) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - STRIP_GROUP);
+                const bool grp = ok & ((PZG_LV(o.N, k) & (G - 1u)) == 0u);
+                if (grp) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - G);
             }
             strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
         PZG_LANES_END
@@ -2347,14 +2356,15 @@ struct Decoder {
         // phase B: the strips, until every lane started where its neighbour ended
         PZG_HOT_ACC(8, tsa);
         PZG_T0(tsb);
-        StripOut o;
+        constexpr uint32_t G = strip_group<FX>();
+        StripOut<G> o;
         PZG_LANES_BEGIN(k)
             PZG_LV(S, k) = PZG_LV(P, k);
             PZG_LV(LIM, k) += C;
             PZG_LV(o.N, k) = 0u;
             PZG_LV(o.STF, k) = 0u;
 #pragma unroll
-            for (uint32_t g = 0; g < STRIP_GROUP; ++g) PZG_LV(o.T[g], k) = 0u;
+            for (uint32_t g = 0; g < G; ++g) PZG_LV(o.T[g], k) = 0u;
         PZG_LANES_END
         uint64_t dirty = ~0ull, stopm = 0ull;
         uint32_t last = 63u;
@@ -2377,7 +2387,7 @@ struct Decoder {
             strip_drain(rd);
             // the last, partial group of every lane that ran: its last four tokens, wherever they end
             PZG_LANES_BEGIN(k)
-                if (lane_bit(dirty, k)) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - STRIP_GROUP);
+                if (lane_bit(dirty, k)) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - G);
             PZG_LANES_END
             // lane k must have started where lane k - 1's chain left its strip; lanes behind the first one that stopped do not count
             LaneVec<uint32_t> NS, PREV;
