@@ -1838,12 +1838,6 @@ struct Decoder {
 #endif
         PZG_MARK("e.v");
         PZG_ACCW(9, t_b);
-#if PZG_STRIP_PREFETCH
-        if (STRIPQ && v != 0u) {
-            strip_consume(v);
-            strip_refill();
-        }
-#endif
         if (__builtin_expect(v == 0u, 0)) {
             PZG_STAT(11, 1);  // a head token for copy_match (or a bail-out of the fast body)
             if (FAST) return EMIT_BAIL;
@@ -1855,12 +1849,6 @@ struct Decoder {
             copy_match(dist, len);
             maybe_flush();
             v = 1u;
-#if PZG_STRIP_PREFETCH
-            if (STRIPQ) {
-                strip_consume(1u);
-                strip_refill();
-            }
-#endif
             if (RES) account_tokens(len, 1u, true);
         } else {
 #if defined(PZG_PROFILE) && PZG_DEVICE_PASS
@@ -1936,11 +1924,11 @@ struct Decoder {
             }
         }
         PZG_MARK("e.shift");
-        if (STRIPQ) {  // the span's next tokens, straight from the wave's token scratch (asked for when v was known)
-#if !PZG_STRIP_PREFETCH
+        if (STRIPQ) {  // the span's next tokens, straight from the wave's token scratch.  (Measured: asking for them as soon as v is
+                       // known -- behind a compiler barrier, or the load is sunk back to here -- loses 2-4 %, with and without a far
+                       // fence that waits only after a flush: the load's latency is not what the segments wait for.)
             strip_consume(v);
             strip_refill();
-#endif
             strip_take();
             return ST_OK;
         }
@@ -2068,9 +2056,6 @@ struct Decoder {
 #ifndef PZG_STRIP_BACK
 #define PZG_STRIP_BACK 768
 #endif
-#ifndef PZG_STRIP_PREFETCH
-#define PZG_STRIP_PREFETCH 1
-#endif
     static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may store per span (a multiple of 4)
 #ifndef PZG_STRIP_GROUP
 #define PZG_STRIP_GROUP 16
@@ -2109,9 +2094,7 @@ struct Decoder {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
-    // the queue-to-be (QTN, s_qn) = the next tokens of the span: the rest of region s_reg from s_idx on, then region s_reg + 1.
-    // Asked for as soon as a segment knows how many tokens it takes, taken over when the segment is done (strip_take): the
-    // load's latency passes behind the segment's own work.
+    // the queue-to-be (QTN, s_qn) = the next tokens of the span: the rest of region s_reg from s_idx on, then region s_reg + 1
     PZG_FN void strip_refill()
     {
         uint32_t n0 = lane_get(SCNT, s_reg) - s_idx;
