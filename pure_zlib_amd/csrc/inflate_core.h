@@ -496,8 +496,8 @@ struct Decoder {
     uint32_t dist_sub_used;      // ... by the distance code
     // strips (strip_span): this wave's token scratch in HBM (null: no strips), the tokens of the span being emitted
     uint32_t *strip;
-    uint32_t s_reg, s_idx, s_last;  // the queue's head is token s_idx of lane s_reg's region; s_last = the span's last region
-    LaneVec<uint32_t> SCNT;         // tokens in each lane's region
+    uint32_t s_rd;                  // the queue's head is token number s_rd of the span
+    LaneVec<uint32_t> SPRE;         // tokens in the regions of lanes 0 .. k
     LaneVec<uint32_t> QTN;          // the queue after the segment in progress (strip_refill)
     uint32_t s_qn;
     int32_t status;
@@ -562,9 +562,7 @@ struct Decoder {
         use_sub = uni(use_sub);
         lit_sub_used = uni(lit_sub_used);
         dist_sub_used = uni(dist_sub_used);
-        s_reg = uni(s_reg);
-        s_idx = uni(s_idx);
-        s_last = uni(s_last);
+        s_rd = uni(s_rd);
         s_qn = uni(s_qn);
         dist_n = uni(dist_n);
         pend_m0 = uni64(pend_m0);
@@ -2094,21 +2092,25 @@ struct Decoder {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
-    // the queue-to-be (QTN, s_qn) = the next tokens of the span: the rest of region s_reg from s_idx on, then region s_reg + 1
+    // the queue-to-be (QTN, s_qn) = the span's tokens from number s_rd on: the rest of the region that token lies in, then the
+    // region behind it.  SPRE[k] = tokens in regions 0 .. k (lanes behind the span's last region repeat the total): the region
+    // is found by one compare and a population count, no loop.
     PZG_FN void strip_refill()
     {
-        uint32_t n0 = lane_get(SCNT, s_reg) - s_idx;
-        while (n0 == 0u && s_reg < s_last) {
-            s_reg += 1u;
-            s_idx = 0u;
-            n0 = lane_get(SCNT, s_reg);
-        }
-        const uint32_t n1 = s_reg < s_last ? lane_get(SCNT, s_reg + 1u) : 0u;
-        const uint32_t a0 = strip_region(s_reg) + s_idx, a1 = strip_region(s_reg + 1u) - n0;
+        LaneVec<bool> BELOW;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(BELOW, k) = PZG_LV(SPRE, k) <= s_rd;
+        PZG_LANES_END
+        const uint32_t r = popc64(lanes_ballot(BELOW));  // (64: the span is used up)
+        const uint32_t rr = r < 63u ? r : 63u;
+        const uint32_t lo = r != 0u ? lane_get(SPRE, rr - (r < 64u ? 1u : 0u)) : 0u;  // tokens in front of region r
+        const uint32_t hi = lane_get(SPRE, rr), hi1 = lane_get(SPRE, rr < 63u ? rr + 1u : 63u);
+        const uint32_t n0 = hi - s_rd, n1 = hi1 - hi;
+        const uint32_t a0 = strip_region(rr) + (s_rd - lo), a1 = strip_region(rr + 1u) - n0;
         PZG_LANES_BEGIN(j)
             PZG_LV(QTN, j) = strip_load((j < n0 ? a0 : a1) + j);  // (past both regions: some word of the scratch, never looked at)
         PZG_LANES_END
-        const uint32_t left = n0 + n1;
+        const uint32_t left = r < 64u ? n0 + n1 : 0u;
         s_qn = left < QCAP ? left : QCAP;
     }
     PZG_FN void strip_take()
@@ -2116,15 +2118,7 @@ struct Decoder {
         QT = QTN;
         qn = s_qn;
     }
-    PZG_FN void strip_consume(uint32_t v)
-    {
-        s_idx += v;
-        uint32_t n = lane_get(SCNT, s_reg);
-        if (s_idx >= n && s_reg < s_last) {  // (v <= qn <= the rest of this region + the next one)
-            s_idx -= n;
-            s_reg += 1u;
-        }
-    }
+    PZG_FN void strip_consume(uint32_t v) { s_rd += v; }
     // the distance code's second level, as spec_sub() for the literal/length code (a distance base can have bit 30 set,
     // so K_SUB is recognised by its stop bit and kind)
     PZG_FN void spec_dsub(Spec &t)
@@ -2401,15 +2395,13 @@ struct Decoder {
         PZG_HOT_ACC(9, tsb);
         PZG_T0(tsc);
         PZG_LANES_BEGIN(k)
-            PZG_LV(SCNT, k) = k <= last ? PZG_LV(o.N, k) : 0u;
+            PZG_LV(SPRE, k) = k <= last ? PZG_LV(o.N, k) : 0u;
         PZG_LANES_END
-        s_reg = 0u;
-        s_idx = 0u;
-        s_last = last;
+        lanes_iscan_add(SPRE);
+        s_rd = 0u;
 #if defined(PZG_STATS) && !PZG_DEVICE_PASS
         {
-            uint32_t tot = 0;
-            for (uint32_t k = 0; k <= last; ++k) tot += lane_get(SCNT, k);
+            const uint32_t tot = lane_get(SPRE, 63u);
             PZG_STAT(13, 1);                 // spans
             PZG_STAT(14, tot);               // their tokens
             PZG_STAT(18, dirty != 0ull ? 1 : 0);
@@ -2786,7 +2778,7 @@ struct Decoder {
         use_sub = 0;
         lit_sub_used = 0;
         dist_sub_used = 0;
-        s_reg = s_idx = s_last = s_qn = 0;
+        s_rd = s_qn = 0;
         pend_m0 = pend_m1 = 0;
         pend_pos = 0;
         qn = 0;
