@@ -2049,7 +2049,8 @@ struct Decoder {
     // a token.
     static constexpr bool STRIPS = !RES;
 #ifndef PZG_STRIP_TMAX
-#define PZG_STRIP_TMAX 128
+#define PZG_STRIP_TMAX 192  // (measured on text / html / mixed / literal-heavy / config 3: 128: 249 / 237 / 260 / 128 / 141 GiB/s; 160: 260 / 242 /
+                            // 269 / 123 / 139; 192: 263 / 241 / 272 / 134 / 141; 224: 261 / 243 / 277 / 127 / 138; 256: 260 / 247 / 277 / 120 / 141)
 #endif
 #ifndef PZG_STRIP_BACK
 #define PZG_STRIP_BACK 768
