@@ -128,8 +128,8 @@ typedef struct pzg_ctx pzg_ctx;
 
 /* Create a context on HIP device `device` (0-based).  One HIP stream + grow-only device
  * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device.
- * Device memory the library takes for itself, grow-only until pzg_shutdown: the kernels' token scratch -- 34.5 KiB per stream-wave
- * of a launch (one wave per stream, at most the residency of the chip: 6,656 waves = 224 MiB on an MI355X), two such arenas per
+ * Device memory the library takes for itself, grow-only until pzg_shutdown: the kernels' token scratch -- 52.5 KiB per stream-wave
+ * of a launch (one wave per stream, at most the residency of the chip: 6,656 waves = 341 MiB on an MI355X), two such arenas per
  * device for PZG_DEVICE_PTRS launches and one per host-path pipeline in use -- beside the host path's staging arenas.  A launch
  * whose scratch cannot be allocated still decodes, by the slower window path alone. */
 PZG_API int  pzg_init(int device, pzg_ctx **out);
