@@ -41,7 +41,7 @@ def log(*a):
 def traffic_from_profiles(args, ring_bits, n):
     """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, counters only) of
     this same command on the committed kernel; recorded in profiles/traffic.json after each profiling session
-    (tests/tools/profile_round.sh).  Returns (bytes or None, where the number comes from)."""
+    (tests/tools/r4_profiles.sh).  Returns (bytes or None, where the number comes from)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
