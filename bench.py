@@ -396,16 +396,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_path:
         h_out = np.empty(int(d_out.numel()), dtype=np.uint8)
         ctx.decompress_many_raw(h_in, in_off, in_len, h_out, out_off, out_cap)  # warm the staging buffers
-        t0h = time.perf_counter()
-        o_len, o_st, _det, _used, _ad = ctx.decompress_many_raw(h_in, in_off, in_len, h_out, out_off, out_cap)
-        dth = time.perf_counter() - t0h
+        dth = None
+        for _ in range(2):  # (the better of two calls, as the page-locked leg below: the copies by the host's helper threads vary with the box)
+            t0h = time.perf_counter()
+            o_len, o_st, _det, _used, _ad = ctx.decompress_many_raw(h_in, in_off, in_len, h_out, out_off, out_cap)
+            dt1 = time.perf_counter() - t0h
+            dth = dt1 if dth is None else min(dth, dt1)
         k0 = int(n // 2)
         ok_h = bool((o_st == 0).all() and (o_len == out_cap).all()
                     and h_out[int(out_off[k0]):int(out_off[k0]) + int(out_cap[k0])].tobytes() == texts[pick[k0]])
         result["host_buffers_variant"] = {
             "GiBps": round(int(out_cap.sum()) / dth / 2**30, 2), "ms": round(dth * 1e3, 1), "ok": ok_h,
             "note": "pageable host arenas in and out through pzg_decompress_many without PZG_DEVICE_PTRS: "
-                    "pinned staging + PCIe both ways + kernel, one call",
+                    "pinned staging + PCIe both ways + kernel, one call (the better of two)",
         }
         del h_out
         # ... and as PAGE-LOCKED arenas (pzg_host_alloc + PZG_HOST_PINNED: what the module mirrors hand over): the copy engines
