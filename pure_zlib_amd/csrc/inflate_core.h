@@ -1924,7 +1924,8 @@ struct Decoder {
         PZG_MARK("e.shift");
         if (STRIPQ) {  // the span's next tokens, straight from the wave's token scratch.  (Measured: asking for them as soon as v is
                        // known -- behind a compiler barrier, or the load is sunk back to here -- loses 2-4 %, with and without a far
-                       // fence that waits only after a flush: the load's latency is not what the segments wait for.)
+                       // fence that waits only after a flush, and also together with the last segment's far bytes waited for only
+                       // in front of this segment's first ring read: these latencies are not what the segments wait for.)
             strip_consume(v);
             strip_refill();
             strip_take();
