@@ -109,7 +109,9 @@ extern "C" {
 
 /* ---- flags ------------------------------------------------------------------- */
 #define PZG_DEVICE_PTRS  1u  /* every pointer argument is device memory on the context's device */
-#define PZG_ASYNC        2u  /* enqueue only (requires PZG_DEVICE_PTRS); caller calls pzg_sync() */
+#define PZG_ASYNC        2u  /* enqueue only (requires PZG_DEVICE_PTRS); caller calls pzg_sync().  Launches enqueued on different
+                              * streams (pzg_set_stream in between) may run at the same time, two at most: a third waits, on its own
+                              * stream, for the first's token scratch (see pzg_init) */
 #define PZG_GZIP         4u  /* EXTENSION (the reference has no gzip: README.md:42-50 TODO): every stream is
                               * one RFC 1952 member (gzip header, deflate, CRC-32 + ISIZE); adler[] then holds the CRC-32 */
 #define PZG_LPT_ORDER    8u  /* device-pointer batches of mixed sizes: launch the longest streams (largest out_cap[]) first; the
