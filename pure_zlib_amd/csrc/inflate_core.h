@@ -1712,11 +1712,7 @@ struct Decoder {
             const uint32_t o = o0 + j;
             ring_store((o < run) & !lane_bit(farm, j), (op32 + o) & RMASK, (uint8_t)PZG_LV(VAL, j), j);
         PZG_LANES_END
-#if defined(PZG_LAB_NOFAR)  // lab timing experiment only (wrong bytes): what the far loads cost
-        if (false) {
-#else
         if (HYBRID) {  // sources older than the ring: the stream's own flushed output (fdelta = op - flushed)
-#endif
             if (RES_HIST) {  // the decoder's history, by position modulo its size
                 PZG_LANES_BEGIN(j)
                     const uint32_t hp = lane_bit(farm, j) ? (op32 + (o0 + j) - PZG_LV(DIST, j)) & HIST_MASK : 0u;
