@@ -497,6 +497,7 @@ struct Decoder {
     // strips (strip_span): this wave's token scratch in HBM (null: no strips), the tokens of the span being emitted
     uint32_t *strip;
     uint32_t s_rd;                  // the queue's head is token number s_rd of the span
+    uint32_t s_poor;                // a span of this block ended after few strips because the guesses kept failing
     LaneVec<uint32_t> SPRE;         // tokens in the regions of lanes 0 .. k
     LaneVec<uint32_t> QTN;          // the queue after the segment in progress (strip_refill)
     uint32_t s_qn;
@@ -563,6 +564,7 @@ struct Decoder {
         lit_sub_used = uni(lit_sub_used);
         dist_sub_used = uni(dist_sub_used);
         s_rd = uni(s_rd);
+        s_poor = uni(s_poor);
         s_qn = uni(s_qn);
         dist_n = uni(dist_n);
         pend_m0 = uni64(pend_m0);
@@ -2071,7 +2073,10 @@ struct Decoder {
 #define PZG_STRIP_CMIN 256
 #endif
     static constexpr uint32_t STRIP_CMIN = PZG_STRIP_CMIN;      // shorter strips are not worth a span
-    static constexpr uint32_t STRIP_ROUNDS = 6u;
+#ifndef PZG_STRIP_ROUNDS
+#define PZG_STRIP_ROUNDS 6
+#endif
+    static constexpr uint32_t STRIP_ROUNDS = PZG_STRIP_ROUNDS;
     static constexpr int STRIP_NA = -2;
     PZG_FN static constexpr uint32_t strip_region(uint32_t k) { return k * STRIP_RSTRIDE + STRIP_GROUP; }
 
@@ -2387,6 +2392,9 @@ struct Decoder {
         if (dirty != 0ull) {  // still a lane that started in the wrong place: the span ends in front of it
             last = ctz64(dirty) - 1u;
             stopm = 0ull;
+            // (input on which the run-ups do not find the chain -- none of the corpora has such a span -- would pay six rounds for
+            // a few strips every time: the rest of the block is left to the windows)
+            if (last < 16u) s_poor = 1u;
         }
         stopper = stopm != 0ull && lane_get(o.STF, last) == 1u;
         const uint32_t pend = lane_get(P, last);
@@ -2449,12 +2457,14 @@ struct Decoder {
     PZG_FN int token_loop()
     {
         bool strips = STRIPS && strip != nullptr;
+        s_poor = 0u;
         for (;;) {
             PZG_T0(tw);
             bool checked;
             bool span_done = false;
             if (strips) {
                 const int ss = strip_span<FX>(checked);
+                if (s_poor) strips = false;
                 if (ss == STRIP_NA) strips = false;
                 else if (ss != ST_OK) return ss;
                 else if (!checked) continue;
@@ -2776,7 +2786,7 @@ struct Decoder {
         use_sub = 0;
         lit_sub_used = 0;
         dist_sub_used = 0;
-        s_rd = s_qn = 0;
+        s_rd = s_qn = s_poor = 0;
         pend_m0 = pend_m1 = 0;
         pend_pos = 0;
         qn = 0;

@@ -22,11 +22,8 @@ class R(C.Structure):
                 ("out_len", C.c_uint64), ("in_used", C.c_uint64)]
 
 
-@pytest.fixture(scope="session")
-def model():
+def _build_model(flags):
     d = os.path.join(ROOT, "tests", "model")
-    # PZG_MODEL_FLAGS: extra -D options for the host model (e.g. -DPZG_PIPE_MIN_RING=11: every ring through hot_loop_pipe())
-    flags = os.environ.get("PZG_MODEL_FLAGS", "").split()
     so = os.path.join(d, "libpzgmodel%s.so" % ("_" + hashlib.md5(" ".join(flags).encode()).hexdigest()[:8] if flags else ""))
     srcs = [os.path.join(d, "model_harness.cpp"), os.path.join(ROOT, "pure_zlib_amd", "csrc", "inflate_core.h"),
             os.path.join(ROOT, "pure_zlib_amd", "csrc", "wave.h")]
@@ -42,6 +39,19 @@ def model():
         assert (M.pzm_decompress_gzip if gzip else M.pzm_decompress)(z, len(z), out, cap, rb, C.byref(r)) == 0
         return r, out.raw[: min(r.out_len, cap)]
     return run
+
+
+@pytest.fixture(scope="session")
+def model():
+    # PZG_MODEL_FLAGS: extra -D options for the host model
+    return _build_model(os.environ.get("PZG_MODEL_FLAGS", "").split())
+
+
+@pytest.fixture(scope="session")
+def model_bad_guesses():
+    """The host model with the strips' run-up cut to 8 bits and ONE round of phase B: nearly every lane starts in the wrong place,
+    spans end after a strip or two and the rest of the block falls back to the windows (strip_span(): s_poor)."""
+    return _build_model(["-DPZG_STRIP_BACK=8", "-DPZG_STRIP_ROUNDS=1"])
 
 
 def same(ro, oo, rm, om):
@@ -144,6 +154,21 @@ def test_model_strips(model, oracle, rb, strips, monkeypatch):
             cap = [len(d) + 64, len(d) // 2][c % 2] if c < 4 else len(d)
             ro, oo = oracle.decompress(zc, cap)
             rm, om = model(zc, cap, rb)
+            assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
+
+
+@pytest.mark.parametrize("rb", [11, 15])
+def test_model_strips_when_the_guesses_fail(model_bad_guesses, oracle, rb):
+    """Nothing about the result may depend on the strips' speculative starts: with the run-up and the repair rounds all but
+    switched off the same streams and corruptions decode to the same results (and the block goes on by windows)."""
+    for seed in range(18):
+        d, z = corpus.strip_case(seed)
+        r, out = model_bad_guesses(z, len(d), rb)
+        assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), seed
+        for c in range(4):
+            zc = corpus.corrupt(z, seed * 16 + c)
+            ro, oo = oracle.decompress(zc, len(d) + 64)
+            rm, om = model_bad_guesses(zc, len(d) + 64, rb)
             assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
 
 
