@@ -497,7 +497,6 @@ struct Decoder {
     // strips (strip_span): this wave's token scratch in HBM (null: no strips), the tokens of the span being emitted
     uint32_t *strip;
     uint32_t s_rd;                  // the queue's head is token number s_rd of the span
-    uint32_t s_poor;                // a span of this block ended after few strips because the guesses kept failing
     LaneVec<uint32_t> SPRE;         // tokens in the regions of lanes 0 .. k
     LaneVec<uint32_t> QTN;          // the queue after the segment in progress (strip_refill)
     uint32_t s_qn;
@@ -564,7 +563,6 @@ struct Decoder {
         lit_sub_used = uni(lit_sub_used);
         dist_sub_used = uni(dist_sub_used);
         s_rd = uni(s_rd);
-        s_poor = uni(s_poor);
         s_qn = uni(s_qn);
         dist_n = uni(dist_n);
         pend_m0 = uni64(pend_m0);
@@ -2288,8 +2286,9 @@ struct Decoder {
 
     // Decodes and emits one span.  STRIP_NA: nothing done (too little input ahead; the windows take over);
     // ST_OK: the span's tokens are all out, the cursor stands behind them -- at a stopper if `stopper`; else an error status.
+    // `poor` is set when the span ended after few strips because the guesses kept failing.
     template <bool FX>
-    PZG_FN int strip_span(bool &stopper)
+    PZG_FN int strip_span(bool &stopper, bool &poor)
     {
         stopper = false;
         const int64_t av = br.avail();
@@ -2394,7 +2393,7 @@ struct Decoder {
             stopm = 0ull;
             // (input on which the run-ups do not find the chain -- none of the corpora has such a span -- would pay six rounds for
             // a few strips every time: the rest of the block is left to the windows)
-            if (last < 16u) s_poor = 1u;
+            if (last < 16u) poor = true;
         }
         stopper = stopm != 0ull && lane_get(o.STF, last) == 1u;
         const uint32_t pend = lane_get(P, last);
@@ -2457,15 +2456,14 @@ struct Decoder {
     PZG_FN int token_loop()
     {
         bool strips = STRIPS && strip != nullptr;
-        s_poor = 0u;
         for (;;) {
             PZG_T0(tw);
             bool checked;
             bool span_done = false;
             if (strips) {
-                const int ss = strip_span<FX>(checked);
-                if (s_poor) strips = false;
-                if (ss == STRIP_NA) strips = false;
+                bool poor = false;
+                const int ss = strip_span<FX>(checked, poor);
+                if (ss == STRIP_NA || poor) strips = false;
                 else if (ss != ST_OK) return ss;
                 else if (!checked) continue;
                 else span_done = true;
@@ -2786,7 +2784,7 @@ struct Decoder {
         use_sub = 0;
         lit_sub_used = 0;
         dist_sub_used = 0;
-        s_rd = s_qn = s_poor = 0;
+        s_rd = s_qn = 0;
         pend_m0 = pend_m1 = 0;
         pend_pos = 0;
         qn = 0;
