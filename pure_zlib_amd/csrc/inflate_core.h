@@ -66,6 +66,13 @@
 #ifndef PZG_HOT_ACC
 #define PZG_HOT_ACC(slot, var)
 #endif
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS && defined(PZG_PROFILE_HOT)  // the parts of a group (seq_group), every wait charged where it stands
+#define PZG_SEQ_T0(var) uint64_t var = __builtin_amdgcn_s_memtime()
+#define PZG_SEQ_ACC(slot, var) (__builtin_amdgcn_s_waitcnt(0x0070), prof[slot] += __builtin_amdgcn_s_memtime() - var, var = __builtin_amdgcn_s_memtime())
+#else
+#define PZG_SEQ_T0(var)
+#define PZG_SEQ_ACC(slot, var)
+#endif
 
 // Lab build of the HOST model only (-DPZG_STATS, tests/tools/model_stats.py): event counts of the token loop
 #if defined(PZG_STATS) && !PZG_DEVICE_PASS
@@ -494,12 +501,15 @@ struct Decoder {
     uint32_t use_sub;            // the block's literal/length code has enough long prefixes: windows do the second lookup
     uint32_t lit_sub_used;       // second-level entries taken by the literal/length code (the distance code's follow)
     uint32_t dist_sub_used;      // ... by the distance code
-    // strips (strip_span): this wave's token scratch in HBM (null: no strips), the tokens of the span being emitted
+    // strips (strip_span): this wave's scratch in HBM (null: no strips), the sequence records of the span being emitted
     uint32_t *strip;
-    uint32_t s_rd;                  // the queue's head is token number s_rd of the span
-    LaneVec<uint32_t> SPRE;         // tokens in the regions of lanes 0 .. k
-    LaneVec<uint32_t> QTN;          // the queue after the segment in progress (strip_refill)
-    uint32_t s_qn;
+    uint32_t s_rd;                  // the group's first record is record number s_rd of the span
+    LaneVec<uint32_t> SPRE;         // records in the regions of lanes 0 .. k
+    LaneVec<uint32_t> QTN;          // the next group's records (seq_refill): lane j holds record s_rd + j
+    uint32_t s_qn;                  // ... how many of them there are (<= 64)
+    uint32_t s_n0;                  // ... of which the first s_n0 lie in region s_rr, the others in region s_rr + 1
+    uint32_t s_rr;
+    uint32_t s_lc;                  // literal bytes of region s_rr that the records in front of s_rd account for
     int32_t status;
     uint32_t detail0, detail1;
     // A segment's bytes from literals and the near ring are stored at once; bytes whose source is older than
@@ -564,6 +574,9 @@ struct Decoder {
         dist_sub_used = uni(dist_sub_used);
         s_rd = uni(s_rd);
         s_qn = uni(s_qn);
+        s_n0 = uni(s_n0);
+        s_rr = uni(s_rr);
+        s_lc = uni(s_lc);
         dist_n = uni(dist_n);
         pend_m0 = uni64(pend_m0);
         pend_m1 = uni64(pend_m1);
@@ -1769,7 +1782,7 @@ struct Decoder {
     // FAST (hot_loop): returns EMIT_BAIL, with nothing changed that emit_segment() would not redo, where the general
     // code has lane-dependent branches -- a flush is due, or the queue's head is a match for copy_match().
     static constexpr int EMIT_BAIL = -1;
-    template <bool FAST, bool STRIPQ = false>
+    template <bool FAST>
     PZG_FN int emit_body()
     {
         PZG_MARK("e.begin");
@@ -1918,15 +1931,6 @@ struct Decoder {
             }
         }
         PZG_MARK("e.shift");
-        if (STRIPQ) {  // the span's next tokens, straight from the wave's token scratch.  (Measured: asking for them as soon as v is
-                       // known -- behind a compiler barrier, or the load is sunk back to here -- loses 2-4 %, with and without a far
-                       // fence that waits only after a flush, and also together with the last segment's far bytes waited for only
-                       // in front of this segment's first ring read: these latencies are not what the segments wait for.)
-            strip_consume(v);
-            strip_refill();
-            strip_take();
-            return ST_OK;
-        }
         // the queue moves up by v tokens
         LaneVec<uint32_t> SRC;
         PZG_LANES_BEGIN(j)
@@ -2028,7 +2032,7 @@ struct Decoder {
     }
 
 
-    // ---- strips (round 4): a long run of input decoded by 64 lanes side by side ------------------------------------
+    // ---- strips (round 4; round 5: sequences): a long run of input decoded by 64 lanes side by side -------------------
     // The windows pay ~140 instructions per 128 input bits -- 128 speculative lane-decodes and a serial walk for ~12 real
     // tokens.  A strip pays ~70 instructions for 64 REAL tokens: the input in front of the cursor is cut into 64 strips of C
     // bits, and lane k decodes strip k token by token (the same LDS lookups and 13 vector instructions as a window's lane),
@@ -2036,36 +2040,40 @@ struct Decoder {
     // its first token starts.  Phase A: it starts STRIP_BACK bits in front of its strip at an arbitrary bit and decodes up to
     // the strip -- DEFLATE's codes re-synchronise: by then the lane is on the stream's real chain of tokens with probability
     // ~0.996 for text (measured: half of all wrong starts are back on the chain after 92 bits, 99 % after 630).  Phase B:
-    // every lane decodes its strip from there and stores the tokens into its own region of the wave's scratch (strip[], four
-    // tokens per store); where lane k - 1's chain leaves its strip must be where lane k started -- lanes for which that is not
-    // so decode again from the right place (and then perhaps the next lane...), at most STRIP_ROUNDS times, after which the
-    // span simply ends in front of the first lane that is still wrong.  It also ends at the first lane that met a stopper (end
-    // of block, a code the tables do not resolve, an error: token_step_checked()'s business, as with the windows) or filled
-    // its region.  emit_body() then takes its tokens from the regions, lane after lane (STRIPQ: one load instead of the queue's
-    // shift), until the span is used up.  Nothing about the result depends on the guesses: a wrong guess costs a round, never
+    // every lane decodes its strip from there; where lane k - 1's chain leaves its strip must be where lane k started -- lanes
+    // for which that is not so decode again from the right place (and then perhaps the next lane...), at most STRIP_ROUNDS
+    // times, after which the span simply ends in front of the first lane that is still wrong.  It also ends at the first lane
+    // that met a stopper (end of block, a code the tables do not resolve, an error: token_step_checked()'s business, as with
+    // the windows) or filled its region.  Nothing about the result depends on the guesses: a wrong guess costs a round, never
     // a token.
+    // Round 5: what phase B writes to the wave's scratch is no longer one dword per token but the stream as SEQUENCES, the way
+    // an LZ77 copier wants it (Deflate.hs:106-120 runInflate alternates exactly these two actions): a run of literal bytes
+    // followed by one match.  A lane's region holds a literal area (one byte per literal, stored 16 at a time) and a record
+    // area (one dword per sequence: literal-run length, match length, distance; stored SEQ_G at a time).  seq_group() then
+    // gives every LANE one whole SEQUENCE -- round 4's segments gave every lane one output BYTE and paid a prefix scan, two
+    // crossbar scatters and two byte gathers per ~100 bytes: 2.3 wave-instructions per output byte, 77 % of a stream's time.
+    // A group of up to 64 sequences (~500 bytes of text) costs one prefix sum, and the bytes move as unaligned dwords.
     static constexpr bool STRIPS = !RES;
 #ifndef PZG_STRIP_TMAX
-#define PZG_STRIP_TMAX 192  // (measured on text / html / mixed / literal-heavy / config 3: 128: 249 / 237 / 260 / 128 / 141 GiB/s; 160: 260 / 242 /
+#define PZG_STRIP_TMAX 192  // (round 4, measured on text / html / mixed / literal-heavy / config 3: 128: 249 / 237 / 260 / 128 / 141 GiB/s; 160: 260 / 242 /
                             // 269 / 123 / 139; 192: 263 / 241 / 272 / 134 / 141; 224: 261 / 243 / 277 / 127 / 138; 256: 260 / 247 / 277 / 120 / 141)
 #endif
 #ifndef PZG_STRIP_BACK
 #define PZG_STRIP_BACK 768
 #endif
-    static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may store per span (a multiple of 4)
-#ifndef PZG_STRIP_GROUP
-#define PZG_STRIP_GROUP 16
+    static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may decode per span (a multiple of 16)
+    static_assert(STRIP_TMAX % 16u == 0u && STRIP_TMAX <= 4096u, "region geometry");
+#ifndef PZG_SEQ_GROUP
+#define PZG_SEQ_GROUP 8
 #endif
-#ifndef PZG_STRIP_GROUP_FX
-#define PZG_STRIP_GROUP_FX 8
-#endif
-    // tokens per store: 16 in dynamic blocks, 8 in fixed ones (measured: 16 is +1 % on text and +7 % on literal-heavy data over 8,
-    // -1.5 % on the 4 KiB fixed-Huffman batch, whose short strips seldom fill a group of 16)
-    template <bool FX> static constexpr uint32_t strip_group() { return FX ? (uint32_t)PZG_STRIP_GROUP_FX : (uint32_t)PZG_STRIP_GROUP; }
-    static constexpr uint32_t STRIP_GROUP = PZG_STRIP_GROUP > PZG_STRIP_GROUP_FX ? PZG_STRIP_GROUP : PZG_STRIP_GROUP_FX;  // the larger: the regions' slack
-    static constexpr uint32_t STRIP_RSTRIDE = STRIP_TMAX + STRIP_GROUP;  // a region: a group of slack (the last, partial group is stored
-                                                                // as the lane's last tokens, which may reach below the region), then the tokens
-    static constexpr uint32_t STRIP_WORDS = 64u * STRIP_RSTRIDE + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
+    // A lane's region of the scratch, byte offsets: 16 bytes of slack | the literal area (STRIP_TMAX bytes from REG_LITA on) |
+    // SEQ_G records of slack | the record area (STRIP_TMAX dwords from REG_RECA on).  The slack in front of an area takes the
+    // lane's last, partial group, which is stored as the lane's LAST 16 literals / SEQ_G records wherever they end.
+    static constexpr uint32_t SEQ_G = PZG_SEQ_GROUP;           // records per store (a power of two)
+    static constexpr uint32_t REG_LITA = 32u;
+    static constexpr uint32_t REG_RECA = (REG_LITA + STRIP_TMAX + 4u * SEQ_G + 31u) & ~31u;
+    static constexpr uint32_t REG_BYTES = (REG_RECA + 4u * STRIP_TMAX + 63u) & ~63u;
+    static constexpr uint32_t STRIP_WORDS = 64u * (REG_BYTES / 4u) + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
     static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits
 #ifndef PZG_STRIP_CMIN
 #define PZG_STRIP_CMIN 256
@@ -2076,7 +2084,15 @@ struct Decoder {
 #endif
     static constexpr uint32_t STRIP_ROUNDS = PZG_STRIP_ROUNDS;
     static constexpr int STRIP_NA = -2;
-    PZG_FN static constexpr uint32_t strip_region(uint32_t k) { return k * STRIP_RSTRIDE + STRIP_GROUP; }
+    PZG_FN static constexpr uint32_t reg_rec(uint32_t k) { return k * (REG_BYTES / 4u) + REG_RECA / 4u; }  // dword index of region k's first record
+    PZG_FN static constexpr uint32_t reg_lit(uint32_t k) { return k * REG_BYTES + REG_LITA; }             // byte offset of its first literal
+
+    // A sequence record:  [14:0] distance - 1   [22:15] match length - 3   [30:23] literals in front of the match (0..255)
+    //                     [31] no match follows (the literal run was cut at 255, or the lane's strip ended in literals)
+    static constexpr uint32_t SEQ_NOMATCH = 0x80000000u;
+    PZG_FN static uint32_t seq_nl(uint32_t rec) { return (rec >> 23) & 255u; }
+    PZG_FN static uint32_t seq_len(uint32_t rec) { return (int32_t)rec < 0 ? 0u : ((rec >> 15) & 255u) + 3u; }
+    PZG_FN static uint32_t seq_dist(uint32_t rec) { return (rec & 0x7fffu) + 1u; }
 
     // the wave's own stores of a moment ago, read back by OTHER lanes: device-scope loads (not served from a stale L1 line)
     PZG_FN uint32_t strip_load(uint32_t i) const
@@ -2087,16 +2103,37 @@ struct Decoder {
         return strip[i];
 #endif
     }
+    // four / one literal bytes at byte offset `off` of the scratch (any alignment: the hardware takes unaligned dword loads)
+    PZG_FN uint32_t lit_load32(uint32_t off) const
+    {
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(strip) + off;
+#if PZG_DEVICE_PASS
+        return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        uint32_t v;
+        __builtin_memcpy(&v, p, 4);
+        return v;
+#endif
+    }
+    PZG_FN uint8_t lit_load8(uint32_t off) const
+    {
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(strip) + off;
+#if PZG_DEVICE_PASS
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        return *p;
+#endif
+    }
     PZG_FN void strip_fence() const
     {
 #if PZG_DEVICE_PASS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
-    // the queue-to-be (QTN, s_qn) = the span's tokens from number s_rd on: the rest of the region that token lies in, then the
-    // region behind it.  SPRE[k] = tokens in regions 0 .. k (lanes behind the span's last region repeat the total): the region
-    // is found by one compare and a population count, no loop.
-    PZG_FN void strip_refill()
+    // The next group's records (QTN, s_qn) = the span's records from number s_rd on: the rest of the region that record lies
+    // in (s_n0 of them), then the region behind it.  SPRE[k] = records in regions 0 .. k (lanes behind the span's last region
+    // repeat the total): the region is found by one compare and a population count, no loop.
+    PZG_FN void seq_refill()
     {
         LaneVec<bool> BELOW;
         PZG_LANES_BEGIN(k)
@@ -2104,22 +2141,19 @@ struct Decoder {
         PZG_LANES_END
         const uint32_t r = popc64(lanes_ballot(BELOW));  // (64: the span is used up)
         const uint32_t rr = r < 63u ? r : 63u;
-        const uint32_t lo = r != 0u ? lane_get(SPRE, rr - (r < 64u ? 1u : 0u)) : 0u;  // tokens in front of region r
+        const uint32_t lo = r != 0u ? lane_get(SPRE, rr - (r < 64u ? 1u : 0u)) : 0u;  // records in front of region r
         const uint32_t hi = lane_get(SPRE, rr), hi1 = lane_get(SPRE, rr < 63u ? rr + 1u : 63u);
         const uint32_t n0 = hi - s_rd, n1 = hi1 - hi;
-        const uint32_t a0 = strip_region(rr) + (s_rd - lo), a1 = strip_region(rr + 1u) - n0;
+        const uint32_t a0 = reg_rec(rr) + (s_rd - lo), a1 = reg_rec(rr + 1u) - n0;
         PZG_LANES_BEGIN(j)
             PZG_LV(QTN, j) = strip_load((j < n0 ? a0 : a1) + j);  // (past both regions: some word of the scratch, never looked at)
         PZG_LANES_END
         const uint32_t left = r < 64u ? n0 + n1 : 0u;
-        s_qn = left < QCAP ? left : QCAP;
+        s_qn = left < 64u ? left : 64u;
+        s_n0 = n0 < 64u ? n0 : 64u;
+        s_rr = rr;
+        if (s_rd == lo) s_lc = 0u;  // the group starts a region
     }
-    PZG_FN void strip_take()
-    {
-        QT = QTN;
-        qn = s_qn;
-    }
-    PZG_FN void strip_consume(uint32_t v) { s_rd += v; }
     // the distance code's second level, as spec_sub() for the literal/length code (a distance base can have bit 30 set,
     // so K_SUB is recognised by its stop bit and kind)
     PZG_FN void spec_dsub(Spec &t)
@@ -2225,24 +2259,30 @@ struct Decoder {
         PZG_STAT(16, 1);  // steps of phase A
         return true;
     }
-    template <uint32_t G>
-    struct StripOut {
-        LaneVec<uint32_t> N, STF;  // tokens stored; 1 = met a stopper, 2 = region full
-        LaneVec<uint32_t> T[G];    // the last tokens, T[G - 1] the newest
+    // what a lane of phase B has produced so far
+    struct SeqOut {
+        LaneVec<uint32_t> N, STF;        // tokens decoded; 1 = met a stopper, 2 = region full
+        LaneVec<uint32_t> NR, NLB, LR;   // records / literal bytes produced; literals since the last record
+        LaneVec<uint32_t> REC[SEQ_G];    // the last records, REC[SEQ_G - 1] the newest
+        LaneVec<uint32_t> LA[4];         // the last 16 literal bytes, the newest in the top byte of LA[3]
     };
-    template <uint32_t G>
-    PZG_FN void strip_store_group(const StripOut<G> &o, uint32_t k, uint32_t at)
+    PZG_FN void seq_store_records(const SeqOut &o, uint32_t k, uint32_t at)  // (dword index)
     {
         uint32_t *q = strip + at;
 #pragma unroll
-        for (uint32_t g = 0; g < G; ++g) q[g] = PZG_LV(o.T[g], k);
+        for (uint32_t g = 0; g < SEQ_G; ++g) q[g] = PZG_LV(o.REC[g], k);
+    }
+    PZG_FN void seq_store_lits(const SeqOut &o, uint32_t k, uint32_t at)  // (byte offset, a multiple of 4)
+    {
+        uint32_t *q = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(strip) + at);
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) q[g] = PZG_LV(o.LA[g], k);
     }
     // ... of phase B, for the lanes of `dirty` that have not reached the end of their strip
     template <bool FX>
-    PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd,
-                             StripOut<strip_group<FX>()> &o, LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
+    PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd, SeqOut &o,
+                             LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
     {
-        constexpr uint32_t G = strip_group<FX>();
         LaneVec<bool> ACT;
         PZG_LANES_BEGIN(k)
             PZG_LV(ACT, k) = lane_bit(dirty, k) & (PZG_LV(o.STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k));
@@ -2255,24 +2295,59 @@ struct Decoder {
             const bool act = PZG_LV(ACT, k), full = PZG_LV(o.N, k) >= STRIP_TMAX, stop = tb >= 128u;
             const bool ok = act & !stop & !full;
             PZG_LV(o.STF, k) = (act & stop) ? 1u : (act & full) ? 2u : PZG_LV(o.STF, k);
-#pragma unroll
-            for (uint32_t g = 0; g + 1u < G; ++g) PZG_LV(o.T[g], k) = ok ? PZG_LV(o.T[g + 1u], k) : PZG_LV(o.T[g], k);
-            PZG_LV(o.T[G - 1u], k) = ok ? tk : PZG_LV(o.T[G - 1u], k);
+            const bool is_m = ok & ((int32_t)tk < 0), is_l = ok & ((int32_t)tk >= 0);
             PZG_LV(o.N, k) += ok ? 1u : 0u;
+            // a literal: its byte enters the 16-byte accumulator from the top (a funnel shift by 8 or by nothing: no selects)
+            const uint32_t sh = is_l ? 8u : 0u;
+            PZG_LV(o.LA[0], k) = funnel(PZG_LV(o.LA[1], k), PZG_LV(o.LA[0], k), sh);
+            PZG_LV(o.LA[1], k) = funnel(PZG_LV(o.LA[2], k), PZG_LV(o.LA[1], k), sh);
+            PZG_LV(o.LA[2], k) = funnel(PZG_LV(o.LA[3], k), PZG_LV(o.LA[2], k), sh);
+            PZG_LV(o.LA[3], k) = funnel(tk >> 8, PZG_LV(o.LA[3], k), sh);
+            const uint32_t nlb = PZG_LV(o.NLB, k) + (is_l ? 1u : 0u), lr = PZG_LV(o.LR, k) + (is_l ? 1u : 0u);
+            PZG_LV(o.NLB, k) = nlb;
+            // a record: a match closes the sequence its literals opened; a run of 255 literals is cut
+            const bool emit = is_m | (is_l & (lr == 255u));
+            const uint32_t a = tk - 0x00030001u;  // (length - 3) << 16 | distance - 1: no borrow (distance >= 1)
+            const uint32_t mrec = (a & 0x7fffu) | (((a >> 16) & 0xffu) << 15) | (lr << 23);
+            const uint32_t rec = is_m ? mrec : (SEQ_NOMATCH | (255u << 23));
+#pragma unroll
+            for (uint32_t g = 0; g + 1u < SEQ_G; ++g) PZG_LV(o.REC[g], k) = emit ? PZG_LV(o.REC[g + 1u], k) : PZG_LV(o.REC[g], k);
+            PZG_LV(o.REC[SEQ_G - 1u], k) = emit ? rec : PZG_LV(o.REC[SEQ_G - 1u], k);
+            const uint32_t nr = PZG_LV(o.NR, k) + (emit ? 1u : 0u);
+            PZG_LV(o.NR, k) = nr;
+            PZG_LV(o.LR, k) = emit ? 0u : lr;
             const uint32_t adv = ok ? tb : 0u;
             PZG_LV(P, k) += adv;
             PZG_SR(R) += adv;
-            {  // a full group of tokens: one aligned store per lane that has one.  (Measured, text / literal-heavy data: groups of 4 / 8 /
-               // 16 tokens 217 / 234 / 237 and 93 / 113 / 120 GiB/s -- the scratch is written in pieces of lines, and the fewer
-               // and larger the pieces the less of it is written twice; every lane's last four tokens every fourth step, wherever
-               // they end -- a quarter of the store instructions, but unaligned and overlapping -- cost text 20 %.)
-                const bool grp = ok & ((PZG_LV(o.N, k) & (G - 1u)) == 0u);
-                if (grp) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - G);
-            }
+            // full groups: one aligned store per lane that has one.  (Round 4, measured on text / literal-heavy data with one dword
+            // per token: groups of 4 / 8 / 16 tokens 217 / 234 / 237 and 93 / 113 / 120 GiB/s -- the scratch is written in pieces of
+            // lines, and the fewer and larger the pieces the less of it is written twice.)
+            if (is_l & ((nlb & 15u) == 0u)) seq_store_lits(o, k, reg_lit(k) + nlb - 16u);
+            if (emit & ((nr & (SEQ_G - 1u)) == 0u)) seq_store_records(o, k, reg_rec(k) + nr - SEQ_G);
             strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
         PZG_LANES_END
         PZG_STAT(17, 1);  // steps of phase B
         return true;
+    }
+    // a lane that ran has reached the end of its strip: the literals it ended in become a last record (no match), and its last,
+    // partial groups are stored -- the last SEQ_G records / 16 literals wherever they end (they may reach into the slack below)
+    PZG_FN void strip_finish_lane(SeqOut &o, uint32_t k)
+    {
+        const uint32_t lr = PZG_LV(o.LR, k);
+        const bool fin = lr != 0u;
+#pragma unroll
+        for (uint32_t g = 0; g + 1u < SEQ_G; ++g) PZG_LV(o.REC[g], k) = fin ? PZG_LV(o.REC[g + 1u], k) : PZG_LV(o.REC[g], k);
+        PZG_LV(o.REC[SEQ_G - 1u], k) = fin ? (SEQ_NOMATCH | (lr << 23)) : PZG_LV(o.REC[SEQ_G - 1u], k);
+        PZG_LV(o.NR, k) += fin ? 1u : 0u;
+        PZG_LV(o.LR, k) = 0u;
+        seq_store_records(o, k, reg_rec(k) + PZG_LV(o.NR, k) - SEQ_G);
+        // (the literal store is made of aligned dwords: the accumulator moves down by the 0-3 bytes that round the count up)
+        const uint32_t nlb = PZG_LV(o.NLB, k), sh = ((0u - nlb) & 3u) << 3;
+        PZG_LV(o.LA[0], k) = funnel(PZG_LV(o.LA[1], k), PZG_LV(o.LA[0], k), sh);
+        PZG_LV(o.LA[1], k) = funnel(PZG_LV(o.LA[2], k), PZG_LV(o.LA[1], k), sh);
+        PZG_LV(o.LA[2], k) = funnel(PZG_LV(o.LA[3], k), PZG_LV(o.LA[2], k), sh);
+        PZG_LV(o.LA[3], k) = funnel(0u, PZG_LV(o.LA[3], k), sh);
+        seq_store_lits(o, k, reg_lit(k) + ((nlb + 3u) & ~3u) - 16u);
     }
     PZG_FN void strip_drain(StripReader &rd)  // what is still landing goes to its slot
     {
@@ -2307,6 +2382,7 @@ struct Decoder {
             const int se = emit_segment();
             if (se) return se;
         }
+        complete_pending();  // (... and the far bytes of the last segment: the groups read the ring)
         const uint64_t pos0 = br.pos();
         const uint32_t r0 = (uint32_t)pos0 & 31u;
         const uint32_t dw0 = (uint32_t)(pos0 >> 5);
@@ -2335,15 +2411,17 @@ struct Decoder {
         // phase B: the strips, until every lane started where its neighbour ended
         PZG_HOT_ACC(8, tsa);
         PZG_T0(tsb);
-        constexpr uint32_t G = strip_group<FX>();
-        StripOut<G> o;
+        SeqOut o;
         PZG_LANES_BEGIN(k)
             PZG_LV(S, k) = PZG_LV(P, k);
             PZG_LV(LIM, k) += C;
             PZG_LV(o.N, k) = 0u;
             PZG_LV(o.STF, k) = 0u;
+            PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
 #pragma unroll
-            for (uint32_t g = 0; g < G; ++g) PZG_LV(o.T[g], k) = 0u;
+            for (uint32_t g = 0; g < SEQ_G; ++g) PZG_LV(o.REC[g], k) = 0u;
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; ++g) PZG_LV(o.LA[g], k) = 0u;
         PZG_LANES_END
         uint64_t dirty = ~0ull, stopm = 0ull;
         uint32_t last = 63u;
@@ -2355,6 +2433,7 @@ struct Decoder {
                         PZG_LV(P, k) = p;
                         PZG_LV(o.N, k) = 0u;
                         PZG_LV(o.STF, k) = 0u;
+                        PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
                         strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
                     }
                 PZG_LANES_END
@@ -2364,9 +2443,8 @@ struct Decoder {
                 if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM, rd.TB, rd.PB)) break;
             }
             strip_drain(rd);
-            // the last, partial group of every lane that ran: its last four tokens, wherever they end
             PZG_LANES_BEGIN(k)
-                if (lane_bit(dirty, k)) strip_store_group(o, k, strip_region(k) + PZG_LV(o.N, k) - G);
+                if (lane_bit(dirty, k)) strip_finish_lane(o, k);
             PZG_LANES_END
             // lane k must have started where lane k - 1's chain left its strip; lanes behind the first one that stopped do not count
             LaneVec<uint32_t> NS, PREV;
@@ -2400,15 +2478,16 @@ struct Decoder {
         PZG_HOT_ACC(9, tsb);
         PZG_T0(tsc);
         PZG_LANES_BEGIN(k)
-            PZG_LV(SPRE, k) = k <= last ? PZG_LV(o.N, k) : 0u;
+            PZG_LV(SPRE, k) = k <= last ? PZG_LV(o.NR, k) : 0u;
         PZG_LANES_END
         lanes_iscan_add(SPRE);
         s_rd = 0u;
+        s_lc = 0u;
 #if defined(PZG_STATS) && !PZG_DEVICE_PASS
         {
             const uint32_t tot = lane_get(SPRE, 63u);
             PZG_STAT(13, 1);                 // spans
-            PZG_STAT(14, tot);               // their tokens
+            PZG_STAT(14, tot);               // their records
             PZG_STAT(18, dirty != 0ull ? 1 : 0);
             PZG_STAT(19, last + 1u);         // lanes that counted
         }
@@ -2419,37 +2498,510 @@ struct Decoder {
         br.start(in, in_len, in_byte0);
         br.drop((uint32_t)endbit & 7u);
         strip_fence();
-        strip_refill();
-        strip_take();
+        seq_refill();
         PZG_HOT_ACC(10, tsc);
         PZG_T0(tse);
-        // segments for as long as tokens are left (the fast body in a loop of its own: see hot_loop())
+        // groups of sequences for as long as records are left (the fast body in a loop of its own: see hot_loop())
         for (;;) {
-            if (strip_hot() == 0u) break;
-            const int se = emit_body<false, true>();
+            const uint32_t why = seq_hot();
+            if (why == SQ_DONE) break;
+            if (why == SQ_FLUSH) {
+                flush_to(op & ~(uint64_t)15u);
+                continue;
+            }
+            const int se = seq_solo();
             if (se) return se;
         }
         PZG_HOT_ACC(11, tse);
         return ST_OK;
     }
 #undef PZG_SR
-    PZG_FN uint32_t strip_hot()
+
+    // ---- the groups: every lane copies one whole sequence -----------------------------------------------------------------
+    // A group is the next (up to 64) records of the span whose output fits SEQ_GLIM bytes.  One prefix sum over (literals +
+    // match length) places every sequence; the lanes then store their literal runs (from the scratch's literal areas) and copy
+    // their matches inside the ring, four bytes per instruction wherever four are left: an unaligned dword read and an
+    // unaligned dword write, the last dword of a run overlapping the one before it instead of a tail of single bytes.
+    // What makes that legal is the order of three things, byte-serial semantics kept (OutputWindow.hs:82-101, Deflate.hs:106-120):
+    //   1. all literal runs of the group (they depend on nothing);
+    //   2. the matches whose source ends in front of the group's first match (H): everything they read is older than the
+    //      group or one of its literals.  Matches older than the ring ("far") read the stream's flushed output instead;
+    //   3. what is left -- matches that read the output of other matches of the same group -- in rounds: the first one still
+    //      waiting can always go, and with it every one whose source ends in front of it.  (Text: one match in 30-50.)
+    // A sequence the lanes cannot take -- a match longer than SEQ_CAP, a distance reaching in front of the output, on the
+    // 32 KiB ring a source the group itself would overwrite -- ends the group in front of it and goes through seq_solo().
+    // Runs that wrap around the ring's end, and matches with a distance below 4 (their dwords would read what they are
+    // writing), are copied byte by byte by loops that run only when a ballot says one is there.
+#ifndef PZG_SEQ_GLIM
+#define PZG_SEQ_GLIM 768
+#endif
+#ifndef PZG_SEQ_CAP
+#define PZG_SEQ_CAP 64
+#endif
+    static constexpr uint32_t SEQ_GLIM = PZG_SEQ_GLIM;  // output bytes of a group, at most (the ring keeps RING - SEQ_GLIM bytes of history "near")
+    static constexpr uint32_t SEQ_CAP = PZG_SEQ_CAP;    // longest match a lane copies by itself
+    static_assert(SEQ_GLIM + SEQ_CAP + 3u + 128u <= 1024u && SEQ_GLIM >= 255u + SEQ_CAP, "far sources end a cache line or more below `flushed`; one sequence always fits");
+    enum : uint32_t { SQ_OK = 0, SQ_DONE = 1, SQ_SOLO = 2, SQ_FLUSH = 3 };
+
+    // Four ring bytes at any address.  (Round 5, measured: unaligned ds_read_b32 / ds_write_b32 work on gfx950 -- and stall the
+    // LDS for ~50 cycles per wave-instruction, SQ_LDS_UNALIGNED_STALL 7.1e9 per launch.  Byte operations whose offsets ride in
+    // the instructions cost no vector instruction more, 8 + 16 LDS cycles per four bytes.  They are inline assembly: left to
+    // itself the compiler merges four byte accesses back into the unaligned dword.  LDS operations complete in order, so the
+    // compiler's own wait counts stay sufficient with these in between; the reads wait for their data themselves.)
+    struct Quad {
+        uint32_t b0, b1, b2, b3;  // one byte each (a register each on the device: ds_read_u8 fills one, ds_write_b8 stores its low byte)
+    };
+    static constexpr uint32_t RING_OFF = (uint32_t)offsetof(WaveLds<RING_BITS>, ring);  // (the wave's LDS image starts at LDS address 0: see BitReader::dma_prefetch)
+    static constexpr uint32_t DUMP_REL = (uint32_t)(offsetof(WaveLds<RING_BITS>, dump) - offsetof(WaveLds<RING_BITS>, ring));
+    // two quads: all eight reads in flight, one wait (idx <= RING - 1: bytes past the ring's end are the tables', read and dropped)
+    PZG_FN void ring_load4x2(uint32_t i0, uint32_t i1, Quad &q0, Quad &q1) const
+    {
+#if PZG_DEVICE_PASS
+        asm volatile("ds_read_u8 %0, %8 offset:%c10\n\tds_read_u8 %1, %8 offset:%c11\n\tds_read_u8 %2, %8 offset:%c12\n\tds_read_u8 %3, %8 offset:%c13\n\t"
+                     "ds_read_u8 %4, %9 offset:%c10\n\tds_read_u8 %5, %9 offset:%c11\n\tds_read_u8 %6, %9 offset:%c12\n\tds_read_u8 %7, %9 offset:%c13\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0.b0), "=&v"(q0.b1), "=&v"(q0.b2), "=&v"(q0.b3), "=&v"(q1.b0), "=&v"(q1.b1), "=&v"(q1.b2), "=&v"(q1.b3)
+                     : "v"(i0), "v"(i1), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+                     : "memory");
+#else
+        const uint8_t *p = L.ring + i0, *q = L.ring + i1;
+        q0.b0 = p[0]; q0.b1 = p[1]; q0.b2 = p[2]; q0.b3 = p[3];
+        q1.b0 = q[0]; q1.b1 = q[1]; q1.b2 = q[2]; q1.b3 = q[3];
+#endif
+    }
+    PZG_FN void ring_load4(uint32_t i0, Quad &q0) const
+    {
+#if PZG_DEVICE_PASS
+        asm volatile("ds_read_u8 %0, %4 offset:%c5\n\tds_read_u8 %1, %4 offset:%c6\n\tds_read_u8 %2, %4 offset:%c7\n\tds_read_u8 %3, %4 offset:%c8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(q0.b0), "=&v"(q0.b1), "=&v"(q0.b2), "=&v"(q0.b3)
+                     : "v"(i0), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+                     : "memory");
+#else
+        const uint8_t *p = L.ring + i0;
+        q0.b0 = p[0]; q0.b1 = p[1]; q0.b2 = p[2]; q0.b3 = p[3];
+#endif
+    }
+    // lane-predicated stores of four bytes without a branch (see ring_store): masked lanes store into the dump.
+    // (The bytes go out last first: see the literal runs of seq_group.)
+    PZG_FN void ring_store4(bool pred, uint32_t idx, const Quad &q, uint32_t lane)
+    {
+        const uint32_t a = pred ? idx : DUMP_REL + lane;  // lane < 64 (the dump has room for 76)
+#if PZG_DEVICE_PASS
+        asm volatile("ds_write_b8 %0, %4 offset:%c8\n\tds_write_b8 %0, %3 offset:%c7\n\tds_write_b8 %0, %2 offset:%c6\n\tds_write_b8 %0, %1 offset:%c5"
+                     :
+                     : "v"(a), "v"(q.b0), "v"(q.b1), "v"(q.b2), "v"(q.b3), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+                     : "memory");
+#else
+        uint8_t *p = L.ring + a;
+        p[3] = (uint8_t)q.b3; p[2] = (uint8_t)q.b2; p[1] = (uint8_t)q.b1; p[0] = (uint8_t)q.b0;
+#endif
+    }
+    // ... of the first `nb` (1..4) bytes of the dword x (bytes 2 and 3 straight from its high half)
+    template <uint32_t NB>
+    PZG_FN void ring_store_dw(bool pred, uint32_t idx, uint32_t x, uint32_t lane)
+    {
+        const uint32_t a = pred ? idx : DUMP_REL + lane;
+#if PZG_DEVICE_PASS
+        const uint32_t y = x >> 8;
+        if (NB == 4u)
+            asm volatile("ds_write_b8_d16_hi %0, %2 offset:%c6\n\tds_write_b8_d16_hi %0, %1 offset:%c5\n\tds_write_b8 %0, %2 offset:%c4\n\tds_write_b8 %0, %1 offset:%c3"
+                         :
+                         : "v"(a), "v"(x), "v"(y), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+                         : "memory");
+        else if (NB == 3u)
+            asm volatile("ds_write_b8_d16_hi %0, %1 offset:%c5\n\tds_write_b8 %0, %2 offset:%c4\n\tds_write_b8 %0, %1 offset:%c3"
+                         :
+                         : "v"(a), "v"(x), "v"(y), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u)
+                         : "memory");
+        else if (NB == 2u)
+            asm volatile("ds_write_b8 %0, %2 offset:%c4\n\tds_write_b8 %0, %1 offset:%c3" : : "v"(a), "v"(x), "v"(y), "n"(RING_OFF), "n"(RING_OFF + 1u) : "memory");
+        else
+            asm volatile("ds_write_b8 %0, %1 offset:%c2" : : "v"(a), "v"(x), "n"(RING_OFF) : "memory");
+#else
+        uint8_t *p = L.ring + a;
+        if (NB > 3u) p[3] = (uint8_t)(x >> 24);
+        if (NB > 2u) p[2] = (uint8_t)(x >> 16);
+        if (NB > 1u) p[1] = (uint8_t)(x >> 8);
+        p[0] = (uint8_t)x;
+#endif
+    }
+    PZG_FN void ring_store32(bool pred, uint32_t idx, uint32_t v, uint32_t lane) { ring_store_dw<4u>(pred, idx, v, lane); }
+    PZG_FN void ring_store16(bool pred, uint32_t idx, uint32_t v, uint32_t lane) { ring_store_dw<2u>(pred, idx, v, lane); }
+    PZG_FN uint32_t far_load32(uint32_t off) const
+    {
+        uint32_t v;
+        __builtin_memcpy(&v, far_base + off, 4);
+        return v;
+    }
+    // the matches of RDY (a subset of the group's near matches): dwords four at a time (the reads of a step are all in flight
+    // before its writes: a lane whose distance is 16 or more never reads what the same step writes), the three-byte matches,
+    // the byte-by-byte ones
+    struct SeqCopy {
+        LaneVec<uint32_t> SM, DM, LEN;   // source / destination ring offsets (reduced), match length
+        LaneVec<bool> NORM, SLOW;
+    };
+    PZG_FN void seq_copy(const SeqCopy &c, const LaneVec<bool> &RDY)
+    {
+        LaneVec<uint32_t> ND;  // dwords to move (0: none)
+        LaneVec<Quad> X[2];
+        LaneVec<bool> ACT[2];
+        PZG_LANES_BEGIN(j)
+            const uint32_t len = PZG_LV(c.LEN, j);
+            PZG_LV(ND, j) = (PZG_LV(RDY, j) & PZG_LV(c.NORM, j) & (len >= 4u)) ? (len + 3u) >> 2 : 0u;
+        PZG_LANES_END
+        for (uint32_t i0 = 0;; i0 += 2u) {
+            PZG_LANES_BEGIN(j)
+                PZG_LV(ACT[0], j) = i0 < PZG_LV(ND, j);
+                PZG_LV(ACT[1], j) = i0 + 1u < PZG_LV(ND, j);
+            PZG_LANES_END
+            if (lanes_ballot(ACT[0]) == 0ull) break;
+            PZG_LANES_BEGIN(j)  // (every read of a step precedes its writes, on the device and in the one-lane model alike)
+                const uint32_t l4 = PZG_LV(c.LEN, j) - 4u;
+                const uint32_t o0 = 4u * i0 < l4 ? 4u * i0 : l4, o1 = 4u * i0 + 4u < l4 ? 4u * i0 + 4u : l4;
+                // (a lane that is not moving reads some bytes of the wave's LDS and drops them)
+                ring_load4x2(PZG_LV(c.SM, j) + (PZG_LV(ACT[0], j) ? o0 : 0u), PZG_LV(c.SM, j) + (PZG_LV(ACT[1], j) ? o1 : 0u), PZG_LV(X[0], j), PZG_LV(X[1], j));
+            PZG_LANES_END
+            PZG_LANES_BEGIN(j)
+                const uint32_t l4 = PZG_LV(c.LEN, j) - 4u;
+                const uint32_t o0 = 4u * i0 < l4 ? 4u * i0 : l4, o1 = 4u * i0 + 4u < l4 ? 4u * i0 + 4u : l4;
+                ring_store4(PZG_LV(ACT[0], j), PZG_LV(c.DM, j) + o0, PZG_LV(X[0], j), j);
+                ring_store4(PZG_LV(ACT[1], j), PZG_LV(c.DM, j) + o1, PZG_LV(X[1], j), j);
+            PZG_LANES_END
+            PZG_STAT(26, 1);  // dword steps (of two)
+        }
+        LaneVec<bool> L3;
+        PZG_LANES_BEGIN(j)
+            PZG_LV(L3, j) = PZG_LV(RDY, j) & PZG_LV(c.NORM, j) & (PZG_LV(c.LEN, j) == 3u);
+        PZG_LANES_END
+        if (lanes_ballot(L3) != 0ull) {
+            PZG_LANES_BEGIN(j)
+                ring_load4(PZG_LV(c.SM, j), PZG_LV(X[0], j));
+            PZG_LANES_END
+            PZG_LANES_BEGIN(j)
+                const Quad &q = PZG_LV(X[0], j);
+                ring_store_dw<3u>(PZG_LV(L3, j), PZG_LV(c.DM, j), q.b0 | (q.b1 << 8) | (q.b2 << 16), j);
+            PZG_LANES_END
+        }
+        LaneVec<bool> SL;
+        PZG_LANES_BEGIN(j)
+            PZG_LV(SL, j) = PZG_LV(RDY, j) & PZG_LV(c.SLOW, j);
+        PZG_LANES_END
+        if (__builtin_expect(lanes_ballot(SL) != 0ull, 0)) {
+            for (uint32_t i = 0;; ++i) {
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(ACT[0], j) = PZG_LV(SL, j) & (i < PZG_LV(c.LEN, j));
+                PZG_LANES_END
+                if (lanes_ballot(ACT[0]) == 0ull) break;
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(X[0], j).b0 = L.ring[(PZG_LV(c.SM, j) + i) & RMASK];
+                PZG_LANES_END
+                PZG_LANES_BEGIN(j)
+                    ring_store(PZG_LV(ACT[0], j), (PZG_LV(c.DM, j) + i) & RMASK, (uint8_t)PZG_LV(X[0], j).b0, j);
+                PZG_LANES_END
+                PZG_STAT(27, 1);  // byte steps
+            }
+        }
+    }
+
+    // One group.  SQ_OK: emitted, the next group's records are on their way; SQ_DONE: the span is used up; SQ_SOLO: the record
+    // at the head is one for seq_solo(); SQ_FLUSH: a flush is due that the fast one cannot do.  Nothing has changed in the
+    // last three cases.
+    // The order of the memory operations is what the group's time depends on (measured: with every load waited for where it
+    // was issued a group took three trips to the L2 in a row and the kernel ran at 160 GiB/s where round 4's ran at 264):
+    // as soon as the group's extent is known the NEXT group's records are asked for, then this group's literals and the far
+    // matches' sources; the matches that read nothing of this group are copied while those are on their way.
+    PZG_FN uint32_t seq_group()
+    {
+        const uint32_t n = s_qn, n0 = s_n0;
+        if (n == 0u) return SQ_DONE;
+        if (__builtin_expect((uint32_t)(op - flushed) >= FLUSH_AT, 0)) {  // whole KiB only (the general flush goes up to op & ~15)
+            const uint64_t to = flushed + ((uint32_t)(op - flushed) & ~1023u);
+            if (!out_aligned() || to > cap) return SQ_FLUSH;
+            flush_span<true>(to);
+        }
+        PZG_SEQ_T0(tq);
+        PZG_MARK("g.begin");
+        const uint32_t op32 = (uint32_t)op;
+        uint32_t op_hi = (uint32_t)(op >> 32);
+#if PZG_DEVICE_PASS
+        asm("" : "+s"(op_hi));  // (opaque: see emit_body)
+#endif
+        const uint32_t hist = (op_hi | (op32 >> 20)) ? 0x100000u : op32 + (RING_BITS == 15 ? hist_extra : 0u);
+        // ---- place the sequences: one prefix sum over (literals + match length), the literal count riding in the high half
+        LaneVec<uint32_t> NL, LEN, DIST, ENDX, MO;
+        PZG_LANES_BEGIN(j)
+            const uint32_t rec = PZG_LV(QTN, j);
+            const bool valid = j < n;
+            const uint32_t nl = valid ? seq_nl(rec) : 0u, len = valid ? seq_len(rec) : 0u;
+            PZG_LV(NL, j) = nl;
+            PZG_LV(LEN, j) = len;
+            PZG_LV(DIST, j) = seq_dist(rec);
+            PZG_LV(ENDX, j) = (nl + len) | (nl << 16);
+        PZG_LANES_END
+        lanes_iscan_add(ENDX);  // (64 x 513 and 64 x 255: both halves stay below 2^16)
+        LaneVec<bool> OVER, BIG, BAD, MIX;
+        PZG_LANES_BEGIN(j)
+            const uint32_t end = PZG_LV(ENDX, j) & 0xffffu, len = PZG_LV(LEN, j), m = end - len;
+            PZG_LV(MO, j) = m;  // the match's first byte, relative to op (its literals end there)
+            PZG_LV(OVER, j) = end > SEQ_GLIM;
+            PZG_LV(BIG, j) = len > SEQ_CAP;
+            PZG_LV(BAD, j) = (len != 0u) & (PZG_LV(DIST, j) > hist + m);  // reaches in front of the output: seq_solo() reports it
+            // the 32 KiB ring keeps nothing else: a source the group's own bytes would overwrite first
+            PZG_LV(MIX, j) = RING_BITS == 15 && (len != 0u) & ((int32_t)(m - PZG_LV(DIST, j)) < (int32_t)(SEQ_GLIM - RING));
+        PZG_LANES_END
+        const uint64_t stopm = lanes_ballot(OVER) | lanes_ballot(BIG) | lanes_ballot(BAD) | (RING_BITS == 15 ? lanes_ballot(MIX) : 0ull);
+        const uint32_t v0 = stopm ? ctz64(stopm) : n;
+        const uint32_t v = v0 < n ? v0 : n;  // sequences of this group
+        if (__builtin_expect(v == 0u, 0)) return SQ_SOLO;
+        const uint32_t endv = lane_get(ENDX, v - 1u), run = endv & 0xffffu, lend_v = endv >> 16;
+        const uint32_t lend_n0 = lane_get(ENDX, n0 - 1u) >> 16;  // literals of the records that lie in region s_rr (n0 >= 1)
+        const uint64_t taken = v >= 64u ? ~0ull : bit_field_mask(v, 0u);
+        PZG_STAT(20, 1);    // groups
+        PZG_STAT(21, v);    // their sequences
+        PZG_STAT(22, run);  // their bytes
+        // ---- the matches: where they read and write
+        SeqCopy c;
+        LaneVec<bool> NEAR, FARL, FARW;
+        LaneVec<uint32_t> SEND;
+        PZG_LANES_BEGIN(j)
+            const uint32_t len = PZG_LV(LEN, j), dist = PZG_LV(DIST, j), m = PZG_LV(MO, j);
+            const bool hasm = lane_bit(taken, j) & (len != 0u);
+            const int32_t srcr = (int32_t)(m - dist);  // relative to op
+            const bool near = HYBRID ? hasm & (srcr >= (int32_t)(run - RING)) : hasm;  // still in the ring when the group's last byte is
+            const uint32_t dm = (op32 + m) & RMASK, sm = (dm - dist) & RMASK;
+            const bool wrap_d = dm + len > RING, wrap_s = sm + len > RING;
+            const bool slow = wrap_d | wrap_s | (dist < 4u) | ((dist < 16u) & (len > dist));
+            PZG_LV(c.LEN, j) = len;
+            PZG_LV(c.DM, j) = dm;
+            PZG_LV(c.SM, j) = sm;
+            PZG_LV(NEAR, j) = near;
+            PZG_LV(c.SLOW, j) = near & slow;
+            PZG_LV(c.NORM, j) = near & !slow;
+            PZG_LV(FARL, j) = HYBRID && (hasm & !near);
+            PZG_LV(FARW, j) = wrap_d;
+            PZG_LV(SEND, j) = (uint32_t)srcr + (len < dist ? len : dist);  // where its source ends (signed, relative to op)
+        PZG_LANES_END
+        const uint64_t nearm = lanes_ballot(NEAR), farm = HYBRID ? lanes_ballot(FARL) & far_okmask : 0ull;
+        // ---- the far matches' sources: asked for.  They end SEQ_GLIM + ... bytes below `flushed` at the least (static_assert
+        // above), in lines that are complete and final (see set_far_base).
+        LaneVec<uint32_t> FO, FND, FX[4];
+        LaneVec<bool> FA[4];
+        if (HYBRID && farm != 0ull) {
+            PZG_STAT(25, 1);
+            far_fence();
+            const uint32_t fdelta = (uint32_t)(op - flushed);
+            PZG_LANES_BEGIN(j)
+                const uint32_t len = PZG_LV(c.LEN, j), l4 = len >= 4u ? len - 4u : 0u;
+                const bool fn = lane_bit(farm, j) & !PZG_LV(FARW, j);
+                const uint32_t nd = fn ? (len + 3u) >> 2 : 0u, fo = 32768u + fdelta + PZG_LV(MO, j) - PZG_LV(DIST, j);  // the source's first byte, from far_base
+                PZG_LV(FND, j) = nd;
+                PZG_LV(FO, j) = fo;
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t off = 4u * u < l4 ? 4u * u : l4;
+                    PZG_LV(FA[u], j) = u < nd;
+#if PZG_DEVICE_PASS
+                    PZG_LV(FX[u], j) = far_load32(u < nd ? fo + off : FAR_IDLE);
+#else
+                    PZG_LV(FX[u], j) = u < nd ? far_load32(fo + off) : 0u;
+#endif
+                }
+            PZG_LANES_END
+        }
+        // ---- the next group's records: asked for now, looked at when this group is done
+        const uint32_t lit_a = reg_lit(s_rr) + s_lc, lit_b = reg_lit(s_rr + 1u) - lend_n0;
+        s_lc = v < n0 ? s_lc + lend_v : lend_v - lend_n0;
+        s_rd += v;
+        seq_refill();
+        PZG_SEQ_ACC(12, tq);
+        PZG_MARK("g.lits");
+        // ---- this group's literals: asked for
+        LaneVec<uint32_t> LAD, DL, X0, X1;
+        LaneVec<bool> FASTL, SLOWL, MORE;
+        PZG_LANES_BEGIN(j)
+            const uint32_t nl = PZG_LV(NL, j), lo = (PZG_LV(ENDX, j) >> 16) - nl;
+            const bool tk = lane_bit(taken, j) & (nl != 0u);
+            const uint32_t la = (j < n0 ? lit_a : lit_b) + lo, dl = (op32 + PZG_LV(MO, j) - nl) & RMASK;
+            const bool wrap = dl + nl > RING;
+            PZG_LV(LAD, j) = la;
+            PZG_LV(DL, j) = dl;
+            PZG_LV(FASTL, j) = tk & !wrap;
+            PZG_LV(SLOWL, j) = tk & wrap;
+            PZG_LV(MORE, j) = tk & !wrap & (nl > 8u);
+            const uint32_t off1 = nl - 4u < 4u ? nl - 4u : 4u;
+            PZG_LV(X0, j) = lit_load32((tk & !wrap) ? la : lit_a);
+            PZG_LV(X1, j) = lit_load32((tk & !wrap & (nl > 4u)) ? la + off1 : lit_a);
+        PZG_LANES_END
+        PZG_SEQ_ACC(13, tq);
+        PZG_MARK("g.matches");
+        // ---- 2a. the matches that read nothing of this group (most of them), while the loads are on their way
+        uint64_t pend = nearm;
+        LaneVec<bool> RDY;
+        if (nearm != 0ull) {
+            PZG_LANES_BEGIN(j)
+                PZG_LV(RDY, j) = PZG_LV(NEAR, j) & ((int32_t)PZG_LV(SEND, j) <= 0);
+            PZG_LANES_END
+            seq_copy(c, RDY);
+            pend &= ~lanes_ballot(RDY);
+            PZG_STAT(23, 1);  // copy rounds
+        }
+        PZG_SEQ_ACC(14, tq);
+        // ---- 1. the literal runs
+        PZG_LANES_BEGIN(j)
+            const uint32_t nl = PZG_LV(NL, j), dl = PZG_LV(DL, j), x0 = PZG_LV(X0, j);
+            const bool f = PZG_LV(FASTL, j);
+            const uint32_t off1 = nl - 4u < 4u ? nl - 4u : 4u;
+            ring_store32(f & (nl >= 4u), dl, x0, j);
+            ring_store32(f & (nl > 4u), dl + off1, PZG_LV(X1, j), j);
+            ring_store_dw<3u>(f & (nl == 3u), dl, x0, j);
+            ring_store_dw<2u>(f & (nl == 2u), dl, x0, j);
+            ring_store_dw<1u>(f & (nl == 1u), dl, x0, j);
+        PZG_LANES_END
+        if (__builtin_expect(lanes_ballot(MORE) != 0ull, 0)) {  // runs of more than 8 literals: two dwords a step
+            LaneVec<bool> A0, A1;
+            for (uint32_t i = 2u;; i += 2u) {
+                PZG_LANES_BEGIN(j)
+                    const uint32_t nd = (PZG_LV(NL, j) + 3u) >> 2;
+                    PZG_LV(A0, j) = PZG_LV(MORE, j) & (i < nd);
+                    PZG_LV(A1, j) = PZG_LV(MORE, j) & (i + 1u < nd);
+                PZG_LANES_END
+                if (lanes_ballot(A0) == 0ull) break;
+                PZG_LANES_BEGIN(j)
+                    const uint32_t l4 = PZG_LV(NL, j) - 4u, o0 = 4u * i < l4 ? 4u * i : l4, o1 = 4u * i + 4u < l4 ? 4u * i + 4u : l4;
+                    const uint32_t y0 = lit_load32(PZG_LV(A0, j) ? PZG_LV(LAD, j) + o0 : lit_a);
+                    const uint32_t y1 = lit_load32(PZG_LV(A1, j) ? PZG_LV(LAD, j) + o1 : lit_a);
+                    ring_store32(PZG_LV(A0, j), PZG_LV(DL, j) + o0, y0, j);
+                    ring_store32(PZG_LV(A1, j), PZG_LV(DL, j) + o1, y1, j);
+                PZG_LANES_END
+            }
+        }
+        if (__builtin_expect(lanes_ballot(SLOWL) != 0ull, 0)) {  // the run that wraps around the ring's end: byte by byte
+            LaneVec<bool> A0;
+            for (uint32_t i = 0;; ++i) {
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(A0, j) = PZG_LV(SLOWL, j) & (i < PZG_LV(NL, j));
+                PZG_LANES_END
+                if (lanes_ballot(A0) == 0ull) break;
+                PZG_LANES_BEGIN(j)
+                    const uint8_t b = lit_load8(PZG_LV(A0, j) ? PZG_LV(LAD, j) + i : lit_a);
+                    ring_store(PZG_LV(A0, j), (PZG_LV(DL, j) + i) & RMASK, b, j);
+                PZG_LANES_END
+            }
+        }
+        PZG_SEQ_ACC(15, tq);
+        PZG_MARK("g.far");
+        // ---- 2b. the far matches
+        if (HYBRID && farm != 0ull) {
+            for (uint32_t i0 = 0;;) {
+                PZG_LANES_BEGIN(j)
+                    const uint32_t len = PZG_LV(c.LEN, j), l4 = len >= 4u ? len - 4u : 0u, dm = PZG_LV(c.DM, j);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t off = 4u * (i0 + u) < l4 ? 4u * (i0 + u) : l4;
+                        ring_store32(PZG_LV(FA[u], j) & (len >= 4u), dm + off, PZG_LV(FX[u], j), j);
+                    }
+                    const bool l3 = (i0 == 0u) & PZG_LV(FA[0], j) & (len == 3u);  // (a three-byte match is one load)
+                    ring_store_dw<3u>(l3, dm, PZG_LV(FX[0], j), j);
+                PZG_LANES_END
+                i0 += 4u;
+                PZG_LANES_BEGIN(j)
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) PZG_LV(FA[u], j) = i0 + u < PZG_LV(FND, j);
+                PZG_LANES_END
+                if (__builtin_expect(lanes_ballot(FA[0]) == 0ull, 1)) break;
+                PZG_LANES_BEGIN(j)  // (matches of more than 16 bytes: the next four dwords)
+                    const uint32_t len = PZG_LV(c.LEN, j), l4 = len >= 4u ? len - 4u : 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t off = 4u * (i0 + u) < l4 ? 4u * (i0 + u) : l4;
+#if PZG_DEVICE_PASS
+                        PZG_LV(FX[u], j) = far_load32(PZG_LV(FA[u], j) ? PZG_LV(FO, j) + off : FAR_IDLE);
+#else
+                        PZG_LV(FX[u], j) = PZG_LV(FA[u], j) ? far_load32(PZG_LV(FO, j) + off) : 0u;
+#endif
+                    }
+                PZG_LANES_END
+            }
+            LaneVec<bool> FS;
+            PZG_LANES_BEGIN(j)
+                PZG_LV(FS, j) = lane_bit(farm, j) & PZG_LV(FARW, j);
+            PZG_LANES_END
+            if (__builtin_expect(lanes_ballot(FS) != 0ull, 0)) {  // a far match whose output wraps around the ring's end
+                for (uint32_t i = 0;; ++i) {
+                    PZG_LANES_BEGIN(j)
+                        PZG_LV(FA[0], j) = PZG_LV(FS, j) & (i < PZG_LV(c.LEN, j));
+                    PZG_LANES_END
+                    if (lanes_ballot(FA[0]) == 0ull) break;
+                    PZG_LANES_BEGIN(j)
+#if PZG_DEVICE_PASS
+                        const uint8_t b = far_base[PZG_LV(FA[0], j) ? PZG_LV(FO, j) + i : FAR_IDLE];
+#else
+                        const uint8_t b = PZG_LV(FA[0], j) ? far_base[PZG_LV(FO, j) + i] : (uint8_t)0;
+#endif
+                        ring_store(PZG_LV(FA[0], j), (PZG_LV(c.DM, j) + i) & RMASK, b, j);
+                    PZG_LANES_END
+                }
+            }
+        }
+        PZG_SEQ_ACC(7, tq);
+        PZG_MARK("g.rounds");
+        // ---- 3. matches that read this group's own bytes: the first one still waiting can always go, and with it every one
+        // whose source ends in front of it
+        while (pend != 0ull) {
+            const uint32_t h = lane_get(MO, ctz64(pend));
+            PZG_LANES_BEGIN(j)
+                PZG_LV(RDY, j) = lane_bit(pend, j) & ((int32_t)PZG_LV(SEND, j) <= (int32_t)h);
+            PZG_LANES_END
+            seq_copy(c, RDY);
+            pend &= ~lanes_ballot(RDY);
+            PZG_STAT(23, 1);
+        }
+        PZG_MARK("g.end");
+        op += run;
+        PZG_SEQ_ACC(6, tq);
+        return SQ_OK;
+    }
+    PZG_FN uint32_t seq_hot()
     {
         uint32_t why;
         for (;;) {
-            if (qn == 0u) {
-                why = 0u;
-                break;
-            }
-            if (emit_body<true, true>() != ST_OK) {
-                why = 1u;
-                break;
-            }
+            why = seq_group();
+            if (why != SQ_OK) break;
         }
 #if PZG_DEVICE_PASS
         asm volatile("" : "+s"(why));
 #endif
         return why;
+    }
+    // The record at the head of the span on its own: its literals by all lanes (64 bytes a step), its match by copy_match().
+    PZG_FN int seq_solo()
+    {
+        PZG_STAT(24, 1);
+        maybe_flush();
+        const uint32_t rec = lane_get(QTN, 0u), nl = seq_nl(rec), len = seq_len(rec), dist = seq_dist(rec);
+        const uint32_t lit_a = reg_lit(s_rr) + s_lc;
+        const uint32_t lane = lane_id();
+#pragma nounroll
+        for (uint32_t k0 = 0; k0 < nl; k0 += PZG_WAVE) {
+            const uint32_t i = k0 + lane;
+            const uint8_t b = lit_load8(lit_a + (i < nl ? i : nl - 1u));
+            ring_store(i < nl, ((uint32_t)op + i) & RMASK, b, lane);
+        }
+        op += nl;
+        maybe_flush();
+        if (len != 0u) {
+            if ((uint64_t)dist > op + (RING_BITS == 15 ? hist_extra : 0u)) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
+#if defined(PZG_PROFILE) && PZG_DEVICE_PASS
+            prof[14] += 1;
+#endif
+            copy_match(dist, len);
+            maybe_flush();
+        }
+        s_lc += nl;
+        s_rd += 1u;
+        seq_refill();
+        return ST_OK;
     }
 
     template <bool FX>
@@ -2463,10 +3015,10 @@ struct Decoder {
             if (strips) {
                 bool poor = false;
                 const int ss = strip_span<FX>(checked, poor);
+                if (ss != ST_OK && ss != STRIP_NA) return ss;  // (an error first: a poor span can end in one too)
                 if (ss == STRIP_NA || poor) strips = false;
-                else if (ss != ST_OK) return ss;
-                else if (!checked) continue;
-                else span_done = true;
+                if (ss == ST_OK && !checked) continue;
+                if (ss == ST_OK) span_done = true;
             }
             if (!span_done) {
             uint32_t why = HL_GENERAL;
@@ -2784,7 +3336,7 @@ struct Decoder {
         use_sub = 0;
         lit_sub_used = 0;
         dist_sub_used = 0;
-        s_rd = s_qn = 0;
+        s_rd = s_qn = s_n0 = s_rr = s_lc = 0;
         pend_m0 = pend_m1 = 0;
         pend_pos = 0;
         qn = 0;

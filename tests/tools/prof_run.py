@@ -13,8 +13,9 @@ L = _ffi.lib()
 L.pzg_prof_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
 nstreams = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
-datas = [corpus.zipf_text(size, i % 64) for i in range(64)]
-if len(sys.argv) > 3 and sys.argv[3] == "fixed":
+kind = sys.argv[3] if len(sys.argv) > 3 else "text"
+datas = [(corpus.html_slice(size, i) if kind == "html" else corpus.skewed_bytes(size, i) if kind == "skewed" else corpus.zipf_text(size, i % 64)) for i in range(64)]
+if kind == "fixed":
     zs = []
     for d in datas:
         co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
@@ -47,6 +48,9 @@ if os.environ.get("PZG_PROF_HDR"):
     names[8:12] = hdr
 if os.environ.get("PZG_PROF_HOT"):  # -DPZG_PROFILE_HOT build
     names[8:12] = ["  hot loop: windows / strips: phase A", "  hot loop: segments / strips: phase B", "  rare window path / strips: compaction", "  strips: emission"]
+    names[12:16] = ["    group: records wait + placement + refill issue", "    group: loads issued, classification", "    group: near matches, round 2a", "    group: literal runs (wait + stores)"]
+    names[7] = "    group: far matches (wait + stores)"
+    names[6] = "    group: later rounds"
 for i, nme in enumerate(names):
     if nme == "-":
         continue
