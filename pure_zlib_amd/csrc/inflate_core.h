@@ -504,12 +504,13 @@ struct Decoder {
     // strips (strip_span): this wave's scratch in HBM (null: no strips), the sequence records of the span being emitted
     uint32_t *strip;
     uint32_t s_rd;                  // the group's first record is record number s_rd of the span
-    LaneVec<uint32_t> SPRE;         // records in the regions of lanes 0 .. k
+    uint32_t s_total, s_cnt;        // records of the span; lanes whose regions hold any
+    LaneVec<uint32_t> CRIDX, CSTA;  // the t-th region that holds records: its lane, and the span's records in front of it (seq_index)
     LaneVec<uint32_t> QTN;          // the next group's records (seq_refill): lane j holds record s_rd + j
+    LaneVec<uint32_t> QINFO;        // ... [7:0] the region it lies in, [15:8] the first lane of this group that lies in the same region,
+                                    // [16] that region is the one the group starts in
     uint32_t s_qn;                  // ... how many of them there are (<= 64)
-    uint32_t s_n0;                  // ... of which the first s_n0 lie in region s_rr, the others in region s_rr + 1
-    uint32_t s_rr;
-    uint32_t s_lc;                  // literal bytes of region s_rr that the records in front of s_rd account for
+    uint32_t s_lc;                  // literal bytes of the region record s_rd lies in that the records in front of s_rd account for
     int32_t status;
     uint32_t detail0, detail1;
     // A segment's bytes from literals and the near ring are stored at once; bytes whose source is older than
@@ -574,8 +575,8 @@ struct Decoder {
         dist_sub_used = uni(dist_sub_used);
         s_rd = uni(s_rd);
         s_qn = uni(s_qn);
-        s_n0 = uni(s_n0);
-        s_rr = uni(s_rr);
+        s_total = uni(s_total);
+        s_cnt = uni(s_cnt);
         s_lc = uni(s_lc);
         dist_n = uni(dist_n);
         pend_m0 = uni64(pend_m0);
@@ -2130,29 +2131,67 @@ struct Decoder {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
-    // The next group's records (QTN, s_qn) = the span's records from number s_rd on: the rest of the region that record lies
-    // in (s_n0 of them), then the region behind it.  SPRE[k] = records in regions 0 .. k (lanes behind the span's last region
-    // repeat the total): the region is found by one compare and a population count, no loop.
-    PZG_FN void seq_refill()
+    // The regions that hold records, in order: CRIDX[t] = the lane of the t-th one, CSTA[t] = the span's records in front of it
+    // (lanes behind the last one: never reached).  Built once per span from the lanes' record counts.
+    PZG_FN void seq_index(const LaneVec<uint32_t> &NR, uint32_t last)
     {
-        LaneVec<bool> BELOW;
+        LaneVec<uint32_t> PRE, EXCL, DEST, KIDX, A, B;
+        LaneVec<bool> NE;
         PZG_LANES_BEGIN(k)
-            PZG_LV(BELOW, k) = PZG_LV(SPRE, k) <= s_rd;
+            const uint32_t n = k <= last ? PZG_LV(NR, k) : 0u;
+            PZG_LV(PRE, k) = n;
+            PZG_LV(NE, k) = n != 0u;
         PZG_LANES_END
-        const uint32_t r = popc64(lanes_ballot(BELOW));  // (64: the span is used up)
-        const uint32_t rr = r < 63u ? r : 63u;
-        const uint32_t lo = r != 0u ? lane_get(SPRE, rr - (r < 64u ? 1u : 0u)) : 0u;  // records in front of region r
-        const uint32_t hi = lane_get(SPRE, rr), hi1 = lane_get(SPRE, rr < 63u ? rr + 1u : 63u);
-        const uint32_t n0 = hi - s_rd, n1 = hi1 - hi;
-        const uint32_t a0 = reg_rec(rr) + (s_rd - lo), a1 = reg_rec(rr + 1u) - n0;
+        const uint64_t ne = lanes_ballot(NE);
+        s_cnt = popc64(ne);
+        lanes_iscan_add(PRE);
+        s_total = lane_get(PRE, 63u);
+        PZG_LANES_BEGIN(k)
+            const uint32_t n = k <= last ? PZG_LV(NR, k) : 0u;
+            PZG_LV(EXCL, k) = PZG_LV(PRE, k) - n;
+            PZG_LV(KIDX, k) = k;
+            PZG_LV(DEST, k) = lane_bit(ne, k) ? mbcnt_k(ne, k) : 63u;  // (lanes without records send to lane 63: a slot only when there are none)
+        PZG_LANES_END
+        lanes_scatter(A, EXCL, DEST);
+        lanes_scatter(B, KIDX, DEST);
+        PZG_LANES_BEGIN(t)
+            PZG_LV(CSTA, t) = t < s_cnt ? PZG_LV(A, t) : 0xffffffffu;
+            PZG_LV(CRIDX, t) = t < s_cnt ? PZG_LV(B, t) : 0u;
+        PZG_LANES_END
+    }
+    // The next group's records (QTN, s_qn) = the span's records from number s_rd on, from however many regions they lie in:
+    // the regions that start inside the group announce themselves at the lane they start at (one crossbar scatter), a count of
+    // the announcements up to its own position tells every lane its region.  True: record s_rd is the first of its region.
+    PZG_FN bool seq_refill()
+    {
+        const uint32_t left = s_total - s_rd, n = left < 64u ? left : 64u;
+        s_qn = n;
+        if (n == 0u) return false;
+        LaneVec<bool> BELOW;
+        PZG_LANES_BEGIN(t)
+            PZG_LV(BELOW, t) = PZG_LV(CSTA, t) <= s_rd;
+        PZG_LANES_END
+        const uint32_t t0 = popc64(lanes_ballot(BELOW)) - 1u;  // (the first region starts at 0: the count is 1 or more)
+        LaneVec<uint32_t> DEST, ONE, MARK, TJ, RJ, SJ;
+        PZG_LANES_BEGIN(t)
+            const uint32_t b = PZG_LV(CSTA, t) - s_rd;  // where region t starts, relative to the group
+            PZG_LV(DEST, t) = b - 1u < 63u ? b : 0u;    // (inside the group, not at its first lane: 1..63)
+            PZG_LV(ONE, t) = 1u;
+        PZG_LANES_END
+        lanes_scatter(MARK, ONE, DEST);
+        const uint64_t marks = lanes_ballot(MARK) >> 1;  // (lane 0 collects what is not sent anywhere)
         PZG_LANES_BEGIN(j)
-            PZG_LV(QTN, j) = strip_load((j < n0 ? a0 : a1) + j);  // (past both regions: some word of the scratch, never looked at)
+            PZG_LV(TJ, j) = t0 + mbcnt_k(marks, j);
         PZG_LANES_END
-        const uint32_t left = r < 64u ? n0 + n1 : 0u;
-        s_qn = left < 64u ? left : 64u;
-        s_n0 = n0 < 64u ? n0 : 64u;
-        s_rr = rr;
-        if (s_rd == lo) s_lc = 0u;  // the group starts a region
+        lanes_gather(RJ, CRIDX, TJ);
+        lanes_gather(SJ, CSTA, TJ);
+        PZG_LANES_BEGIN(j)
+            const uint32_t rj = PZG_LV(RJ, j), rel = PZG_LV(SJ, j) - s_rd;  // (signed: the group's first region starts at or in front of it)
+            const uint32_t fl = (int32_t)rel > 0 ? rel : 0u;
+            PZG_LV(QTN, j) = strip_load(j < n ? reg_rec(rj) + (j - rel) : reg_rec(0u));
+            PZG_LV(QINFO, j) = rj | (fl << 8) | ((PZG_LV(TJ, j) == t0 ? 1u : 0u) << 16);
+        PZG_LANES_END
+        return lane_get(CSTA, t0) == s_rd;
     }
     // the distance code's second level, as spec_sub() for the literal/length code (a distance base can have bit 30 set,
     // so K_SUB is recognised by its stop bit and kind)
@@ -2247,6 +2286,7 @@ struct Decoder {
             PZG_LV(ACT, k) = PZG_LV(P, k) < PZG_LV(LIM, k);
         PZG_LANES_END
         if (lanes_ballot(ACT) == 0ull) return false;
+        PZG_MARK("sa.begin");
         PZG_LANES_BEGIN(k)
             strip_merge(PZG_LV(T, k), PZG_LV(PD, k), PZG_SR(L0), PZG_SR(L1));
             uint32_t tb, tk;
@@ -2256,6 +2296,7 @@ struct Decoder {
             PZG_SR(R) += adv;
             strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
         PZG_LANES_END
+        PZG_MARK("sa.end");
         PZG_STAT(16, 1);  // steps of phase A
         return true;
     }
@@ -2288,6 +2329,7 @@ struct Decoder {
             PZG_LV(ACT, k) = lane_bit(dirty, k) & (PZG_LV(o.STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k));
         PZG_LANES_END
         if (lanes_ballot(ACT) == 0ull) return false;
+        PZG_MARK("sb.begin");
         PZG_LANES_BEGIN(k)
             strip_merge(PZG_LV(T, k), PZG_LV(PD, k), PZG_SR(L0), PZG_SR(L1));
             uint32_t tb, tk;
@@ -2326,6 +2368,7 @@ struct Decoder {
             if (emit & ((nr & (SEQ_G - 1u)) == 0u)) seq_store_records(o, k, reg_rec(k) + nr - SEQ_G);
             strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
         PZG_LANES_END
+        PZG_MARK("sb.end");
         PZG_STAT(17, 1);  // steps of phase B
         return true;
     }
@@ -2477,17 +2520,13 @@ struct Decoder {
         const uint32_t pend = lane_get(P, last);
         PZG_HOT_ACC(9, tsb);
         PZG_T0(tsc);
-        PZG_LANES_BEGIN(k)
-            PZG_LV(SPRE, k) = k <= last ? PZG_LV(o.NR, k) : 0u;
-        PZG_LANES_END
-        lanes_iscan_add(SPRE);
+        seq_index(o.NR, last);
         s_rd = 0u;
         s_lc = 0u;
 #if defined(PZG_STATS) && !PZG_DEVICE_PASS
         {
-            const uint32_t tot = lane_get(SPRE, 63u);
             PZG_STAT(13, 1);                 // spans
-            PZG_STAT(14, tot);               // their records
+            PZG_STAT(14, s_total);           // their records
             PZG_STAT(18, dirty != 0ull ? 1 : 0);
             PZG_STAT(19, last + 1u);         // lanes that counted
         }
@@ -2543,161 +2582,185 @@ struct Decoder {
     static_assert(SEQ_GLIM + SEQ_CAP + 3u + 128u <= 1024u && SEQ_GLIM >= 255u + SEQ_CAP, "far sources end a cache line or more below `flushed`; one sequence always fits");
     enum : uint32_t { SQ_OK = 0, SQ_DONE = 1, SQ_SOLO = 2, SQ_FLUSH = 3 };
 
-    // Four ring bytes at any address.  (Round 5, measured: unaligned ds_read_b32 / ds_write_b32 work on gfx950 -- and stall the
-    // LDS for ~50 cycles per wave-instruction, SQ_LDS_UNALIGNED_STALL 7.1e9 per launch.  Byte operations whose offsets ride in
-    // the instructions cost no vector instruction more, 8 + 16 LDS cycles per four bytes.  They are inline assembly: left to
-    // itself the compiler merges four byte accesses back into the unaligned dword.  LDS operations complete in order, so the
-    // compiler's own wait counts stay sufficient with these in between; the reads wait for their data themselves.)
-    struct Quad {
-        uint32_t b0, b1, b2, b3;  // one byte each (a register each on the device: ds_read_u8 fills one, ds_write_b8 stores its low byte)
-    };
+    // Ring bytes at any address, by byte operations whose offsets ride in the instructions.  (Round 5, measured: unaligned
+    // ds_read_b32 / ds_write_b32 work on gfx950 -- and stall the LDS for ~50 cycles per wave-instruction,
+    // SQ_LDS_UNALIGNED_STALL 7.1e9 per launch; and the compiler merges four byte accesses written in C++ back into exactly that
+    // dword.)  On the device they are inline assembly that runs under a lane mask put into EXEC -- no select of a dump address,
+    // no lane-dependent branch: the copies of a group cost the vector unit their compares and little else.  LDS operations
+    // complete in order, so the compiler's own wait counts stay sufficient with these in between; the reads wait for their data
+    // themselves.  In the one-lane host model the same functions are plain loops over the lanes of the mask.
     static constexpr uint32_t RING_OFF = (uint32_t)offsetof(WaveLds<RING_BITS>, ring);  // (the wave's LDS image starts at LDS address 0: see BitReader::dma_prefetch)
     static constexpr uint32_t DUMP_REL = (uint32_t)(offsetof(WaveLds<RING_BITS>, dump) - offsetof(WaveLds<RING_BITS>, ring));
-    // two quads: all eight reads in flight, one wait (idx <= RING - 1: bytes past the ring's end are the tables', read and dropped)
-    PZG_FN void ring_load4x2(uint32_t i0, uint32_t i1, Quad &q0, Quad &q1) const
+    struct Quad {
+        uint8_t b[4];
+    };
+    // bytes [OFF, OFF + 4) of the lanes of m0 and [OFF + 4, OFF + 8) of the lanes of m1 go from ring offset SM to ring offset DM:
+    // all eight reads in flight, one wait, the writes (last byte first: see the literal runs of seq_group)
+    template <uint32_t OFF>
+    PZG_FN void lds_copy4x2(const LaneVec<uint32_t> &SM, const LaneVec<uint32_t> &DM, uint64_t m0, uint64_t m1)
     {
 #if PZG_DEVICE_PASS
-        asm volatile("ds_read_u8 %0, %8 offset:%c10\n\tds_read_u8 %1, %8 offset:%c11\n\tds_read_u8 %2, %8 offset:%c12\n\tds_read_u8 %3, %8 offset:%c13\n\t"
-                     "ds_read_u8 %4, %9 offset:%c10\n\tds_read_u8 %5, %9 offset:%c11\n\tds_read_u8 %6, %9 offset:%c12\n\tds_read_u8 %7, %9 offset:%c13\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(q0.b0), "=&v"(q0.b1), "=&v"(q0.b2), "=&v"(q0.b3), "=&v"(q1.b0), "=&v"(q1.b1), "=&v"(q1.b2), "=&v"(q1.b3)
-                     : "v"(i0), "v"(i1), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+        uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
+        uint64_t sv;
+        asm volatile("s_mov_b64 %8, exec\n\t"
+                     "s_mov_b64 exec, %11\n\t"
+                     "ds_read_u8 %0, %9 offset:%c13\n\tds_read_u8 %1, %9 offset:%c14\n\tds_read_u8 %2, %9 offset:%c15\n\tds_read_u8 %3, %9 offset:%c16\n\t"
+                     "s_mov_b64 exec, %12\n\t"
+                     "ds_read_u8 %4, %9 offset:%c17\n\tds_read_u8 %5, %9 offset:%c18\n\tds_read_u8 %6, %9 offset:%c19\n\tds_read_u8 %7, %9 offset:%c20\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "ds_write_b8 %10, %7 offset:%c20\n\tds_write_b8 %10, %6 offset:%c19\n\tds_write_b8 %10, %5 offset:%c18\n\tds_write_b8 %10, %4 offset:%c17\n\t"
+                     "s_mov_b64 exec, %11\n\t"
+                     "ds_write_b8 %10, %3 offset:%c16\n\tds_write_b8 %10, %2 offset:%c15\n\tds_write_b8 %10, %1 offset:%c14\n\tds_write_b8 %10, %0 offset:%c13\n\t"
+                     "s_mov_b64 exec, %8"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&s"(sv)
+                     : "v"(SM.v), "v"(DM.v), "s"(m0), "s"(m1), "n"(RING_OFF + OFF), "n"(RING_OFF + OFF + 1u), "n"(RING_OFF + OFF + 2u),
+                       "n"(RING_OFF + OFF + 3u), "n"(RING_OFF + OFF + 4u), "n"(RING_OFF + OFF + 5u), "n"(RING_OFF + OFF + 6u), "n"(RING_OFF + OFF + 7u)
                      : "memory");
 #else
-        const uint8_t *p = L.ring + i0, *q = L.ring + i1;
-        q0.b0 = p[0]; q0.b1 = p[1]; q0.b2 = p[2]; q0.b3 = p[3];
-        q1.b0 = q[0]; q1.b1 = q[1]; q1.b2 = q[2]; q1.b3 = q[3];
+        LaneVec<Quad> A, B;
+        for (uint32_t j = 0; j < 64u; ++j)  // (every read of a step precedes its writes, as on the device)
+            for (uint32_t t = 0; t < 4u; ++t) {
+                if ((m0 >> j) & 1u) A.v[j].b[t] = L.ring[SM.v[j] + OFF + t];
+                if ((m1 >> j) & 1u) B.v[j].b[t] = L.ring[SM.v[j] + OFF + 4u + t];
+            }
+        for (uint32_t j = 0; j < 64u; ++j)
+            for (uint32_t t = 4u; t-- > 0u;) {
+                if ((m1 >> j) & 1u) L.ring[DM.v[j] + OFF + 4u + t] = B.v[j].b[t];
+                if ((m0 >> j) & 1u) L.ring[DM.v[j] + OFF + t] = A.v[j].b[t];
+            }
 #endif
     }
-    PZG_FN void ring_load4(uint32_t i0, Quad &q0) const
+    // four bytes of the lanes of m4 from ST to DT, three bytes of the lanes of m3 from S3 to D3
+    PZG_FN void lds_copy_tail(const LaneVec<uint32_t> &ST, const LaneVec<uint32_t> &DT, uint64_t m4, const LaneVec<uint32_t> &S3,
+                              const LaneVec<uint32_t> &D3, uint64_t m3)
     {
 #if PZG_DEVICE_PASS
-        asm volatile("ds_read_u8 %0, %4 offset:%c5\n\tds_read_u8 %1, %4 offset:%c6\n\tds_read_u8 %2, %4 offset:%c7\n\tds_read_u8 %3, %4 offset:%c8\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(q0.b0), "=&v"(q0.b1), "=&v"(q0.b2), "=&v"(q0.b3)
-                     : "v"(i0), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+        uint32_t r0, r1, r2, r3, r4, r5, r6;
+        uint64_t sv;
+        asm volatile("s_mov_b64 %7, exec\n\t"
+                     "s_mov_b64 exec, %12\n\t"
+                     "ds_read_u8 %0, %8 offset:%c14\n\tds_read_u8 %1, %8 offset:%c15\n\tds_read_u8 %2, %8 offset:%c16\n\tds_read_u8 %3, %8 offset:%c17\n\t"
+                     "s_mov_b64 exec, %13\n\t"
+                     "ds_read_u8 %4, %10 offset:%c14\n\tds_read_u8 %5, %10 offset:%c15\n\tds_read_u8 %6, %10 offset:%c16\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "ds_write_b8 %11, %6 offset:%c16\n\tds_write_b8 %11, %5 offset:%c15\n\tds_write_b8 %11, %4 offset:%c14\n\t"
+                     "s_mov_b64 exec, %12\n\t"
+                     "ds_write_b8 %9, %3 offset:%c17\n\tds_write_b8 %9, %2 offset:%c16\n\tds_write_b8 %9, %1 offset:%c15\n\tds_write_b8 %9, %0 offset:%c14\n\t"
+                     "s_mov_b64 exec, %7"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&s"(sv)
+                     : "v"(ST.v), "v"(DT.v), "v"(S3.v), "v"(D3.v), "s"(m4), "s"(m3), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
                      : "memory");
 #else
-        const uint8_t *p = L.ring + i0;
-        q0.b0 = p[0]; q0.b1 = p[1]; q0.b2 = p[2]; q0.b3 = p[3];
+        LaneVec<Quad> A, B;
+        for (uint32_t j = 0; j < 64u; ++j)
+            for (uint32_t t = 0; t < 4u; ++t) {
+                if ((m4 >> j) & 1u) A.v[j].b[t] = L.ring[ST.v[j] + t];
+                if (((m3 >> j) & 1u) && t < 3u) B.v[j].b[t] = L.ring[S3.v[j] + t];
+            }
+        for (uint32_t j = 0; j < 64u; ++j)
+            for (uint32_t t = 4u; t-- > 0u;) {
+                if (((m3 >> j) & 1u) && t < 3u) L.ring[D3.v[j] + t] = B.v[j].b[t];
+                if ((m4 >> j) & 1u) L.ring[DT.v[j] + t] = A.v[j].b[t];
+            }
 #endif
     }
-    // lane-predicated stores of four bytes without a branch (see ring_store): masked lanes store into the dump.
-    // (The bytes go out last first: see the literal runs of seq_group.)
-    PZG_FN void ring_store4(bool pred, uint32_t idx, const Quad &q, uint32_t lane)
+    // the dword X goes to ring offset A: byte t of the lanes of m[t] (a lane's masks are nested: m[3] in m[2] in m[1] in m[0])
+    PZG_FN void lds_put_bytes(const LaneVec<uint32_t> &A, const LaneVec<uint32_t> &X, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3)
     {
-        const uint32_t a = pred ? idx : DUMP_REL + lane;  // lane < 64 (the dump has room for 76)
 #if PZG_DEVICE_PASS
-        asm volatile("ds_write_b8 %0, %4 offset:%c8\n\tds_write_b8 %0, %3 offset:%c7\n\tds_write_b8 %0, %2 offset:%c6\n\tds_write_b8 %0, %1 offset:%c5"
-                     :
-                     : "v"(a), "v"(q.b0), "v"(q.b1), "v"(q.b2), "v"(q.b3), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+        uint32_t y;
+        uint64_t sv;
+        asm volatile("s_mov_b64 %1, exec\n\t"
+                     "s_mov_b64 exec, %7\n\t"
+                     "v_lshrrev_b32 %0, 8, %3\n\t"
+                     "ds_write_b8_d16_hi %2, %0 offset:%c11\n\t"
+                     "s_mov_b64 exec, %6\n\t"
+                     "ds_write_b8_d16_hi %2, %3 offset:%c10\n\t"
+                     "s_mov_b64 exec, %5\n\t"
+                     "v_lshrrev_b32 %0, 8, %3\n\t"
+                     "ds_write_b8 %2, %0 offset:%c9\n\t"
+                     "s_mov_b64 exec, %4\n\t"
+                     "ds_write_b8 %2, %3 offset:%c8\n\t"
+                     "s_mov_b64 exec, %1"
+                     : "=&v"(y), "=&s"(sv)
+                     : "v"(A.v), "v"(X.v), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
                      : "memory");
 #else
-        uint8_t *p = L.ring + a;
-        p[3] = (uint8_t)q.b3; p[2] = (uint8_t)q.b2; p[1] = (uint8_t)q.b1; p[0] = (uint8_t)q.b0;
+        for (uint32_t j = 0; j < 64u; ++j) {
+            if ((m3 >> j) & 1u) L.ring[A.v[j] + 3u] = (uint8_t)(X.v[j] >> 24);
+            if ((m2 >> j) & 1u) L.ring[A.v[j] + 2u] = (uint8_t)(X.v[j] >> 16);
+            if ((m1 >> j) & 1u) L.ring[A.v[j] + 1u] = (uint8_t)(X.v[j] >> 8);
+            if ((m0 >> j) & 1u) L.ring[A.v[j]] = (uint8_t)X.v[j];
+        }
 #endif
     }
-    // ... of the first `nb` (1..4) bytes of the dword x (bytes 2 and 3 straight from its high half)
-    template <uint32_t NB>
-    PZG_FN void ring_store_dw(bool pred, uint32_t idx, uint32_t x, uint32_t lane)
+    // ... all four bytes of the lanes of m
+    PZG_FN void lds_put_dword(const LaneVec<uint32_t> &A, const LaneVec<uint32_t> &X, uint64_t m)
     {
-        const uint32_t a = pred ? idx : DUMP_REL + lane;
 #if PZG_DEVICE_PASS
-        const uint32_t y = x >> 8;
-        if (NB == 4u)
-            asm volatile("ds_write_b8_d16_hi %0, %2 offset:%c6\n\tds_write_b8_d16_hi %0, %1 offset:%c5\n\tds_write_b8 %0, %2 offset:%c4\n\tds_write_b8 %0, %1 offset:%c3"
-                         :
-                         : "v"(a), "v"(x), "v"(y), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
-                         : "memory");
-        else if (NB == 3u)
-            asm volatile("ds_write_b8_d16_hi %0, %1 offset:%c5\n\tds_write_b8 %0, %2 offset:%c4\n\tds_write_b8 %0, %1 offset:%c3"
-                         :
-                         : "v"(a), "v"(x), "v"(y), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u)
-                         : "memory");
-        else if (NB == 2u)
-            asm volatile("ds_write_b8 %0, %2 offset:%c4\n\tds_write_b8 %0, %1 offset:%c3" : : "v"(a), "v"(x), "v"(y), "n"(RING_OFF), "n"(RING_OFF + 1u) : "memory");
-        else
-            asm volatile("ds_write_b8 %0, %1 offset:%c2" : : "v"(a), "v"(x), "n"(RING_OFF) : "memory");
+        uint32_t y;
+        uint64_t sv;
+        asm volatile("s_mov_b64 %1, exec\n\t"
+                     "s_mov_b64 exec, %4\n\t"
+                     "v_lshrrev_b32 %0, 8, %3\n\t"
+                     "ds_write_b8_d16_hi %2, %0 offset:%c8\n\tds_write_b8_d16_hi %2, %3 offset:%c7\n\tds_write_b8 %2, %0 offset:%c6\n\tds_write_b8 %2, %3 offset:%c5\n\t"
+                     "s_mov_b64 exec, %1"
+                     : "=&v"(y), "=&s"(sv)
+                     : "v"(A.v), "v"(X.v), "s"(m), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
+                     : "memory");
 #else
-        uint8_t *p = L.ring + a;
-        if (NB > 3u) p[3] = (uint8_t)(x >> 24);
-        if (NB > 2u) p[2] = (uint8_t)(x >> 16);
-        if (NB > 1u) p[1] = (uint8_t)(x >> 8);
-        p[0] = (uint8_t)x;
+        lds_put_bytes(A, X, m, m, m, m);
 #endif
     }
-    PZG_FN void ring_store32(bool pred, uint32_t idx, uint32_t v, uint32_t lane) { ring_store_dw<4u>(pred, idx, v, lane); }
-    PZG_FN void ring_store16(bool pred, uint32_t idx, uint32_t v, uint32_t lane) { ring_store_dw<2u>(pred, idx, v, lane); }
     PZG_FN uint32_t far_load32(uint32_t off) const
     {
         uint32_t v;
         __builtin_memcpy(&v, far_base + off, 4);
         return v;
     }
-    // the matches of RDY (a subset of the group's near matches): dwords four at a time (the reads of a step are all in flight
-    // before its writes: a lane whose distance is 16 or more never reads what the same step writes), the three-byte matches,
-    // the byte-by-byte ones
+    // The group's near matches: where they read (SM) and write (DM) in the ring, and the lanes that move dwords (norm4: four
+    // bytes or more, NB whole quads from the front and one that ENDS with the match, ST -> DT -- it overlaps the one before it
+    // instead of a tail of single bytes), three bytes (norm3), or go byte by byte (slow: a run that wraps around the ring's end,
+    // a distance below 16 that the match is longer than).
     struct SeqCopy {
-        LaneVec<uint32_t> SM, DM, LEN;   // source / destination ring offsets (reduced), match length
-        LaneVec<bool> NORM, SLOW;
+        LaneVec<uint32_t> SM, DM, LEN, NB, ST, DT;
+        uint64_t norm4, norm3, slow;
     };
-    PZG_FN void seq_copy(const SeqCopy &c, const LaneVec<bool> &RDY)
+    template <uint32_t T>
+    PZG_FN void seq_copy_trips(const SeqCopy &c, uint64_t m4)
     {
-        LaneVec<uint32_t> ND;  // dwords to move (0: none)
-        LaneVec<Quad> X[2];
-        LaneVec<bool> ACT[2];
-        PZG_LANES_BEGIN(j)
-            const uint32_t len = PZG_LV(c.LEN, j);
-            PZG_LV(ND, j) = (PZG_LV(RDY, j) & PZG_LV(c.NORM, j) & (len >= 4u)) ? (len + 3u) >> 2 : 0u;
-        PZG_LANES_END
-        for (uint32_t i0 = 0;; i0 += 2u) {
+        if constexpr (T < SEQ_CAP / 8u) {
+            LaneVec<bool> A0, A1;
             PZG_LANES_BEGIN(j)
-                PZG_LV(ACT[0], j) = i0 < PZG_LV(ND, j);
-                PZG_LV(ACT[1], j) = i0 + 1u < PZG_LV(ND, j);
+                PZG_LV(A0, j) = 2u * T < PZG_LV(c.NB, j);
+                PZG_LV(A1, j) = 2u * T + 1u < PZG_LV(c.NB, j);
             PZG_LANES_END
-            if (lanes_ballot(ACT[0]) == 0ull) break;
-            PZG_LANES_BEGIN(j)  // (every read of a step precedes its writes, on the device and in the one-lane model alike)
-                const uint32_t l4 = PZG_LV(c.LEN, j) - 4u;
-                const uint32_t o0 = 4u * i0 < l4 ? 4u * i0 : l4, o1 = 4u * i0 + 4u < l4 ? 4u * i0 + 4u : l4;
-                // (a lane that is not moving reads some bytes of the wave's LDS and drops them)
-                ring_load4x2(PZG_LV(c.SM, j) + (PZG_LV(ACT[0], j) ? o0 : 0u), PZG_LV(c.SM, j) + (PZG_LV(ACT[1], j) ? o1 : 0u), PZG_LV(X[0], j), PZG_LV(X[1], j));
-            PZG_LANES_END
-            PZG_LANES_BEGIN(j)
-                const uint32_t l4 = PZG_LV(c.LEN, j) - 4u;
-                const uint32_t o0 = 4u * i0 < l4 ? 4u * i0 : l4, o1 = 4u * i0 + 4u < l4 ? 4u * i0 + 4u : l4;
-                ring_store4(PZG_LV(ACT[0], j), PZG_LV(c.DM, j) + o0, PZG_LV(X[0], j), j);
-                ring_store4(PZG_LV(ACT[1], j), PZG_LV(c.DM, j) + o1, PZG_LV(X[1], j), j);
-            PZG_LANES_END
+            const uint64_t m0 = m4 & lanes_ballot(A0), m1 = m4 & lanes_ballot(A1);
+            if (m0 == 0ull) return;
+            lds_copy4x2<8u * T>(c.SM, c.DM, m0, m1);
             PZG_STAT(26, 1);  // dword steps (of two)
+            seq_copy_trips<T + 1u>(c, m4);
         }
-        LaneVec<bool> L3;
-        PZG_LANES_BEGIN(j)
-            PZG_LV(L3, j) = PZG_LV(RDY, j) & PZG_LV(c.NORM, j) & (PZG_LV(c.LEN, j) == 3u);
-        PZG_LANES_END
-        if (lanes_ballot(L3) != 0ull) {
-            PZG_LANES_BEGIN(j)
-                ring_load4(PZG_LV(c.SM, j), PZG_LV(X[0], j));
-            PZG_LANES_END
-            PZG_LANES_BEGIN(j)
-                const Quad &q = PZG_LV(X[0], j);
-                ring_store_dw<3u>(PZG_LV(L3, j), PZG_LV(c.DM, j), q.b0 | (q.b1 << 8) | (q.b2 << 16), j);
-            PZG_LANES_END
-        }
-        LaneVec<bool> SL;
-        PZG_LANES_BEGIN(j)
-            PZG_LV(SL, j) = PZG_LV(RDY, j) & PZG_LV(c.SLOW, j);
-        PZG_LANES_END
-        if (__builtin_expect(lanes_ballot(SL) != 0ull, 0)) {
+    }
+    // ... those of `rdy` are copied
+    PZG_FN void seq_copy(const SeqCopy &c, uint64_t rdy)
+    {
+        const uint64_t m4 = rdy & c.norm4, m3 = rdy & c.norm3, sl = rdy & c.slow;
+        if (m4 != 0ull) seq_copy_trips<0u>(c, m4);
+        lds_copy_tail(c.ST, c.DT, m4, c.SM, c.DM, m3);
+        if (__builtin_expect(sl != 0ull, 0)) {
+            LaneVec<bool> ACT;
+            LaneVec<uint32_t> X;
             for (uint32_t i = 0;; ++i) {
                 PZG_LANES_BEGIN(j)
-                    PZG_LV(ACT[0], j) = PZG_LV(SL, j) & (i < PZG_LV(c.LEN, j));
+                    PZG_LV(ACT, j) = lane_bit(sl, j) & (i < PZG_LV(c.LEN, j));
                 PZG_LANES_END
-                if (lanes_ballot(ACT[0]) == 0ull) break;
-                PZG_LANES_BEGIN(j)
-                    PZG_LV(X[0], j).b0 = L.ring[(PZG_LV(c.SM, j) + i) & RMASK];
+                if (lanes_ballot(ACT) == 0ull) break;
+                PZG_LANES_BEGIN(j)  // (every read of a step precedes its writes, on the device and in the one-lane model alike)
+                    PZG_LV(X, j) = L.ring[(PZG_LV(c.SM, j) + i) & RMASK];
                 PZG_LANES_END
                 PZG_LANES_BEGIN(j)
-                    ring_store(PZG_LV(ACT[0], j), (PZG_LV(c.DM, j) + i) & RMASK, (uint8_t)PZG_LV(X[0], j).b0, j);
+                    ring_store(PZG_LV(ACT, j), (PZG_LV(c.DM, j) + i) & RMASK, (uint8_t)PZG_LV(X, j), j);
                 PZG_LANES_END
                 PZG_STAT(27, 1);  // byte steps
             }
@@ -2713,7 +2776,7 @@ struct Decoder {
     // matches' sources; the matches that read nothing of this group are copied while those are on their way.
     PZG_FN uint32_t seq_group()
     {
-        const uint32_t n = s_qn, n0 = s_n0;
+        const uint32_t n = s_qn;
         if (n == 0u) return SQ_DONE;
         if (__builtin_expect((uint32_t)(op - flushed) >= FLUSH_AT, 0)) {  // whole KiB only (the general flush goes up to op & ~15)
             const uint64_t to = flushed + ((uint32_t)(op - flushed) & ~1023u);
@@ -2740,29 +2803,27 @@ struct Decoder {
             PZG_LV(ENDX, j) = (nl + len) | (nl << 16);
         PZG_LANES_END
         lanes_iscan_add(ENDX);  // (64 x 513 and 64 x 255: both halves stay below 2^16)
-        LaneVec<bool> OVER, BIG, BAD, MIX;
+        LaneVec<bool> OVER, BAD, MIX;
         PZG_LANES_BEGIN(j)
             const uint32_t end = PZG_LV(ENDX, j) & 0xffffu, len = PZG_LV(LEN, j), m = end - len;
             PZG_LV(MO, j) = m;  // the match's first byte, relative to op (its literals end there)
             PZG_LV(OVER, j) = end > SEQ_GLIM;
-            PZG_LV(BIG, j) = len > SEQ_CAP;
             PZG_LV(BAD, j) = (len != 0u) & (PZG_LV(DIST, j) > hist + m);  // reaches in front of the output: seq_solo() reports it
             // the 32 KiB ring keeps nothing else: a source the group's own bytes would overwrite first
             PZG_LV(MIX, j) = RING_BITS == 15 && (len != 0u) & ((int32_t)(m - PZG_LV(DIST, j)) < (int32_t)(SEQ_GLIM - RING));
         PZG_LANES_END
-        const uint64_t stopm = lanes_ballot(OVER) | lanes_ballot(BIG) | lanes_ballot(BAD) | (RING_BITS == 15 ? lanes_ballot(MIX) : 0ull);
+        const uint64_t stopm = lanes_ballot(OVER) | lanes_ballot(BAD) | (RING_BITS == 15 ? lanes_ballot(MIX) : 0ull);
         const uint32_t v0 = stopm ? ctz64(stopm) : n;
         const uint32_t v = v0 < n ? v0 : n;  // sequences of this group
         if (__builtin_expect(v == 0u, 0)) return SQ_SOLO;
         const uint32_t endv = lane_get(ENDX, v - 1u), run = endv & 0xffffu, lend_v = endv >> 16;
-        const uint32_t lend_n0 = lane_get(ENDX, n0 - 1u) >> 16;  // literals of the records that lie in region s_rr (n0 >= 1)
         const uint64_t taken = v >= 64u ? ~0ull : bit_field_mask(v, 0u);
         PZG_STAT(20, 1);    // groups
         PZG_STAT(21, v);    // their sequences
         PZG_STAT(22, run);  // their bytes
         // ---- the matches: where they read and write
         SeqCopy c;
-        LaneVec<bool> NEAR, FARL, FARW;
+        LaneVec<bool> NEAR, FARL, FARW, SLOW, N4, N3, COOP;
         LaneVec<uint32_t> SEND;
         PZG_LANES_BEGIN(j)
             const uint32_t len = PZG_LV(LEN, j), dist = PZG_LV(DIST, j), m = PZG_LV(MO, j);
@@ -2771,17 +2832,27 @@ struct Decoder {
             const bool near = HYBRID ? hasm & (srcr >= (int32_t)(run - RING)) : hasm;  // still in the ring when the group's last byte is
             const uint32_t dm = (op32 + m) & RMASK, sm = (dm - dist) & RMASK;
             const bool wrap_d = dm + len > RING, wrap_s = sm + len > RING;
-            const bool slow = wrap_d | wrap_s | (dist < 4u) | ((dist < 16u) & (len > dist));
+            const bool slow = wrap_d | wrap_s | ((dist < 16u) & ((len > dist) | (dist < 4u)));
+            const bool big = len > SEQ_CAP;  // all lanes together, when its turn comes (seq_coop)
             PZG_LV(c.LEN, j) = len;
             PZG_LV(c.DM, j) = dm;
             PZG_LV(c.SM, j) = sm;
-            PZG_LV(NEAR, j) = near;
-            PZG_LV(c.SLOW, j) = near & slow;
-            PZG_LV(c.NORM, j) = near & !slow;
-            PZG_LV(FARL, j) = HYBRID && (hasm & !near);
+            PZG_LV(c.NB, j) = (len - 1u) >> 2;
+            PZG_LV(c.ST, j) = sm + len - 4u;
+            PZG_LV(c.DT, j) = dm + len - 4u;
+            PZG_LV(NEAR, j) = near | (hasm & big);
+            PZG_LV(COOP, j) = hasm & big;
+            PZG_LV(SLOW, j) = near & slow & !big;
+            PZG_LV(N4, j) = near & !slow & !big & (len >= 4u);
+            PZG_LV(N3, j) = near & !slow & (len == 3u);
+            PZG_LV(FARL, j) = HYBRID && (hasm & !near & !big);
             PZG_LV(FARW, j) = wrap_d;
             PZG_LV(SEND, j) = (uint32_t)srcr + (len < dist ? len : dist);  // where its source ends (signed, relative to op)
         PZG_LANES_END
+        c.norm4 = lanes_ballot(N4);
+        c.norm3 = lanes_ballot(N3);
+        c.slow = lanes_ballot(SLOW);
+        const uint64_t coopm = lanes_ballot(COOP);
         const uint64_t nearm = lanes_ballot(NEAR), farm = HYBRID ? lanes_ballot(FARL) & far_okmask : 0ull;
         // ---- the far matches' sources: asked for.  They end SEQ_GLIM + ... bytes below `flushed` at the least (static_assert
         // above), in lines that are complete and final (see set_far_base).
@@ -2810,19 +2881,30 @@ struct Decoder {
             PZG_LANES_END
         }
         // ---- the next group's records: asked for now, looked at when this group is done
-        const uint32_t lit_a = reg_lit(s_rr) + s_lc, lit_b = reg_lit(s_rr + 1u) - lend_n0;
-        s_lc = v < n0 ? s_lc + lend_v : lend_v - lend_n0;
+        LaneVec<uint32_t> INFO, LOE, FLV, FLI, CL;
+        PZG_LANES_BEGIN(j)
+            PZG_LV(INFO, j) = PZG_LV(QINFO, j);
+            PZG_LV(FLI, j) = (PZG_LV(QINFO, j) >> 8) & 63u;
+            PZG_LV(LOE, j) = (PZG_LV(ENDX, j) >> 16) - PZG_LV(NL, j);  // the group's literals in front of the lane's
+        PZG_LANES_END
+        const uint32_t lc0 = s_lc, lit_a = reg_lit(lane_get(QINFO, 0u) & 255u);  // (lit_a: a valid place of the scratch, for the lanes that load nothing)
         s_rd += v;
-        seq_refill();
+        const bool at_start = seq_refill();
+        lanes_gather(FLV, LOE, FLI);  // ... in front of the first lane of its region
+        PZG_LANES_BEGIN(j)
+            PZG_LV(CL, j) = PZG_LV(LOE, j) + PZG_LV(NL, j) - PZG_LV(FLV, j) + (((PZG_LV(INFO, j) >> 16) & 1u) ? lc0 : 0u);  // its region's literals up to and including its own
+        PZG_LANES_END
+        s_lc = at_start ? 0u : lane_get(CL, v - 1u);
+        (void)lend_v;
         PZG_SEQ_ACC(12, tq);
         PZG_MARK("g.lits");
         // ---- this group's literals: asked for
         LaneVec<uint32_t> LAD, DL, X0, X1;
         LaneVec<bool> FASTL, SLOWL, MORE;
         PZG_LANES_BEGIN(j)
-            const uint32_t nl = PZG_LV(NL, j), lo = (PZG_LV(ENDX, j) >> 16) - nl;
+            const uint32_t nl = PZG_LV(NL, j);
             const bool tk = lane_bit(taken, j) & (nl != 0u);
-            const uint32_t la = (j < n0 ? lit_a : lit_b) + lo, dl = (op32 + PZG_LV(MO, j) - nl) & RMASK;
+            const uint32_t la = reg_lit(PZG_LV(INFO, j) & 255u) + PZG_LV(CL, j) - nl, dl = (op32 + PZG_LV(MO, j) - nl) & RMASK;
             const bool wrap = dl + nl > RING;
             PZG_LV(LAD, j) = la;
             PZG_LV(DL, j) = dl;
@@ -2837,27 +2919,33 @@ struct Decoder {
         PZG_MARK("g.matches");
         // ---- 2a. the matches that read nothing of this group (most of them), while the loads are on their way
         uint64_t pend = nearm;
-        LaneVec<bool> RDY;
         if (nearm != 0ull) {
+            LaneVec<bool> RDY;
             PZG_LANES_BEGIN(j)
-                PZG_LV(RDY, j) = PZG_LV(NEAR, j) & ((int32_t)PZG_LV(SEND, j) <= 0);
+                PZG_LV(RDY, j) = (int32_t)PZG_LV(SEND, j) <= 0;
             PZG_LANES_END
-            seq_copy(c, RDY);
-            pend &= ~lanes_ballot(RDY);
+            const uint64_t rdy = nearm & lanes_ballot(RDY) & ~coopm;
+            seq_copy(c, rdy);
+            pend &= ~rdy;
             PZG_STAT(23, 1);  // copy rounds
         }
         PZG_SEQ_ACC(14, tq);
-        // ---- 1. the literal runs
-        PZG_LANES_BEGIN(j)
-            const uint32_t nl = PZG_LV(NL, j), dl = PZG_LV(DL, j), x0 = PZG_LV(X0, j);
-            const bool f = PZG_LV(FASTL, j);
-            const uint32_t off1 = nl - 4u < 4u ? nl - 4u : 4u;
-            ring_store32(f & (nl >= 4u), dl, x0, j);
-            ring_store32(f & (nl > 4u), dl + off1, PZG_LV(X1, j), j);
-            ring_store_dw<3u>(f & (nl == 3u), dl, x0, j);
-            ring_store_dw<2u>(f & (nl == 2u), dl, x0, j);
-            ring_store_dw<1u>(f & (nl == 1u), dl, x0, j);
-        PZG_LANES_END
+        // ---- 1. the literal runs: byte t of the first dword where the run has more than t bytes, the second dword ends with the run
+        {
+            LaneVec<bool> G2, G3, G4, G5;
+            LaneVec<uint32_t> DL1;
+            PZG_LANES_BEGIN(j)
+                const uint32_t nl = PZG_LV(NL, j);
+                const bool f = PZG_LV(FASTL, j);
+                PZG_LV(G2, j) = f & (nl >= 2u);
+                PZG_LV(G3, j) = f & (nl >= 3u);
+                PZG_LV(G4, j) = f & (nl >= 4u);
+                PZG_LV(G5, j) = f & (nl > 4u);
+                PZG_LV(DL1, j) = PZG_LV(DL, j) + (nl - 4u < 4u ? nl - 4u : 4u);
+            PZG_LANES_END
+            lds_put_bytes(DL, X0, lanes_ballot(FASTL), lanes_ballot(G2), lanes_ballot(G3), lanes_ballot(G4));
+            lds_put_dword(DL1, X1, lanes_ballot(G5));
+        }
         if (__builtin_expect(lanes_ballot(MORE) != 0ull, 0)) {  // runs of more than 8 literals: two dwords a step
             LaneVec<bool> A0, A1;
             for (uint32_t i = 2u;; i += 2u) {
@@ -2867,13 +2955,16 @@ struct Decoder {
                     PZG_LV(A1, j) = PZG_LV(MORE, j) & (i + 1u < nd);
                 PZG_LANES_END
                 if (lanes_ballot(A0) == 0ull) break;
+                LaneVec<uint32_t> Y0, Y1, D0, D1;
                 PZG_LANES_BEGIN(j)
                     const uint32_t l4 = PZG_LV(NL, j) - 4u, o0 = 4u * i < l4 ? 4u * i : l4, o1 = 4u * i + 4u < l4 ? 4u * i + 4u : l4;
-                    const uint32_t y0 = lit_load32(PZG_LV(A0, j) ? PZG_LV(LAD, j) + o0 : lit_a);
-                    const uint32_t y1 = lit_load32(PZG_LV(A1, j) ? PZG_LV(LAD, j) + o1 : lit_a);
-                    ring_store32(PZG_LV(A0, j), PZG_LV(DL, j) + o0, y0, j);
-                    ring_store32(PZG_LV(A1, j), PZG_LV(DL, j) + o1, y1, j);
+                    PZG_LV(Y0, j) = lit_load32(PZG_LV(A0, j) ? PZG_LV(LAD, j) + o0 : lit_a);
+                    PZG_LV(Y1, j) = lit_load32(PZG_LV(A1, j) ? PZG_LV(LAD, j) + o1 : lit_a);
+                    PZG_LV(D0, j) = PZG_LV(DL, j) + o0;
+                    PZG_LV(D1, j) = PZG_LV(DL, j) + o1;
                 PZG_LANES_END
+                lds_put_dword(D0, Y0, lanes_ballot(A0));
+                lds_put_dword(D1, Y1, lanes_ballot(A1));
             }
         }
         if (__builtin_expect(lanes_ballot(SLOWL) != 0ull, 0)) {  // the run that wraps around the ring's end: byte by byte
@@ -2894,16 +2985,21 @@ struct Decoder {
         // ---- 2b. the far matches
         if (HYBRID && farm != 0ull) {
             for (uint32_t i0 = 0;;) {
+                LaneVec<uint32_t> FD[4];
+                LaneVec<bool> F3;
                 PZG_LANES_BEGIN(j)
                     const uint32_t len = PZG_LV(c.LEN, j), l4 = len >= 4u ? len - 4u : 0u, dm = PZG_LV(c.DM, j);
 #pragma unroll
                     for (uint32_t u = 0; u < 4u; ++u) {
-                        const uint32_t off = 4u * (i0 + u) < l4 ? 4u * (i0 + u) : l4;
-                        ring_store32(PZG_LV(FA[u], j) & (len >= 4u), dm + off, PZG_LV(FX[u], j), j);
+                        PZG_LV(FD[u], j) = dm + (4u * (i0 + u) < l4 ? 4u * (i0 + u) : l4);
+                        PZG_LV(FA[u], j) = PZG_LV(FA[u], j) & (len >= 4u);
                     }
-                    const bool l3 = (i0 == 0u) & PZG_LV(FA[0], j) & (len == 3u);  // (a three-byte match is one load)
-                    ring_store_dw<3u>(l3, dm, PZG_LV(FX[0], j), j);
+                    PZG_LV(F3, j) = (i0 == 0u) & (PZG_LV(FND, j) != 0u) & (len == 3u);  // (a three-byte match is one load)
                 PZG_LANES_END
+                const uint64_t f3 = lanes_ballot(F3);
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) lds_put_dword(FD[u], FX[u], lanes_ballot(FA[u]));
+                lds_put_bytes(c.DM, FX[0], f3, f3, f3, 0ull);
                 i0 += 4u;
                 PZG_LANES_BEGIN(j)
 #pragma unroll
@@ -2949,18 +3045,77 @@ struct Decoder {
         // ---- 3. matches that read this group's own bytes: the first one still waiting can always go, and with it every one
         // whose source ends in front of it
         while (pend != 0ull) {
-            const uint32_t h = lane_get(MO, ctz64(pend));
+            const uint32_t first = ctz64(pend);
+            const uint32_t h = lane_get(MO, first);
+            if (__builtin_expect((coopm >> first) & 1ull, 0)) {  // a long match: everything in front of it is in place
+                seq_coop(op32, h, lane_get(DIST, first), lane_get(LEN, first), run);
+                pend &= ~(1ull << first);
+                PZG_STAT(24, 1);
+                continue;
+            }
+            LaneVec<bool> RDY;
             PZG_LANES_BEGIN(j)
-                PZG_LV(RDY, j) = lane_bit(pend, j) & ((int32_t)PZG_LV(SEND, j) <= (int32_t)h);
+                PZG_LV(RDY, j) = (int32_t)PZG_LV(SEND, j) <= (int32_t)h;
             PZG_LANES_END
-            seq_copy(c, RDY);
-            pend &= ~lanes_ballot(RDY);
+            const uint64_t rdy = pend & lanes_ballot(RDY) & ~coopm;
+            seq_copy(c, rdy);
+            pend &= ~rdy;
             PZG_STAT(23, 1);
         }
         PZG_MARK("g.end");
         op += run;
         PZG_SEQ_ACC(6, tq);
         return SQ_OK;
+    }
+    // A match longer than SEQ_CAP at offset m of the group, by all lanes together (copy_match()'s general path, with the group's
+    // notion of what is still in the ring: the group's literals and earlier matches have overwritten what is older than
+    // op + run - RING).  Every source byte lies in front of the match: for dist < len the pattern repeats with period dist.
+    PZG_FN void seq_coop(uint32_t op32, uint32_t m, uint32_t dist, uint32_t len, uint32_t run)
+    {
+        const uint32_t lane = lane_id();
+        const uint32_t dst0 = op32 + m, src0 = dst0 - dist;
+        const uint32_t fdelta = (uint32_t)(op - flushed);
+        constexpr uint32_t MAXCH = (258u + PZG_WAVE - 1u) / PZG_WAVE;
+        uint8_t v[MAXCH];
+        const bool overlap = dist < len;
+#if PZG_DEVICE_PASS
+        const float rd = overlap ? __builtin_amdgcn_rcpf((float)dist) : 0.0f;
+#endif
+#pragma unroll
+        for (uint32_t c = 0; c < MAXCH; ++c) {
+            const uint32_t k = c * PZG_WAVE + lane;
+            if (c * PZG_WAVE < len) {  // wave-uniform
+                uint32_t off = k;
+                if (overlap) {
+#if PZG_DEVICE_PASS
+                    uint32_t q = (uint32_t)(((float)k + 0.5f) * rd);
+                    off = k - q * dist;
+                    off = off >= dist ? off - dist : off;
+#else
+                    off = k % dist;
+#endif
+                }
+                off = k < len ? off : 0u;
+                v[c] = L.ring[(src0 + off) & RMASK];
+                if (HYBRID) {
+                    const bool far = (k < len) & ((int32_t)(m + off - dist) < (int32_t)(run - RING));
+                    if (ballot(far) & far_okmask) {
+                        far_fence();
+#if PZG_DEVICE_PASS
+                        const uint8_t fb = far_base[far ? 32768u + fdelta + m + off - dist : FAR_IDLE];
+#else
+                        const uint8_t fb = far ? far_base[32768u + fdelta + m + off - dist] : (uint8_t)0;
+#endif
+                        v[c] = far ? fb : v[c];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < MAXCH; ++c) {
+            const uint32_t k = c * PZG_WAVE + lane;
+            if (c * PZG_WAVE < len) ring_store(k < len, (dst0 + k) & RMASK, v[c], lane);
+        }
     }
     PZG_FN uint32_t seq_hot()
     {
@@ -2980,7 +3135,7 @@ struct Decoder {
         PZG_STAT(24, 1);
         maybe_flush();
         const uint32_t rec = lane_get(QTN, 0u), nl = seq_nl(rec), len = seq_len(rec), dist = seq_dist(rec);
-        const uint32_t lit_a = reg_lit(s_rr) + s_lc;
+        const uint32_t lit_a = reg_lit(lane_get(QINFO, 0u) & 255u) + s_lc;
         const uint32_t lane = lane_id();
 #pragma nounroll
         for (uint32_t k0 = 0; k0 < nl; k0 += PZG_WAVE) {
@@ -3000,7 +3155,7 @@ struct Decoder {
         }
         s_lc += nl;
         s_rd += 1u;
-        seq_refill();
+        if (seq_refill()) s_lc = 0u;
         return ST_OK;
     }
 
@@ -3336,7 +3491,7 @@ struct Decoder {
         use_sub = 0;
         lit_sub_used = 0;
         dist_sub_used = 0;
-        s_rd = s_qn = s_n0 = s_rr = s_lc = 0;
+        s_rd = s_qn = s_total = s_cnt = s_lc = 0;
         pend_m0 = pend_m1 = 0;
         pend_pos = 0;
         qn = 0;
