@@ -2045,7 +2045,7 @@ struct Decoder {
     // for which that is not so decode again from the right place (and then perhaps the next lane...), at most STRIP_ROUNDS
     // times, after which the span simply ends in front of the first lane that is still wrong.  It also ends at the first lane
     // that met a stopper (end of block, a code the tables do not resolve, an error: token_step_checked()'s business, as with
-    // the windows) or filled its region.  Nothing about the result depends on the guesses: a wrong guess costs a round, never
+    // the windows).  Nothing about the result depends on the guesses: a wrong guess costs a round, never
     // a token.
     // Round 5: what phase B writes to the wave's scratch is no longer one dword per token but the stream as SEQUENCES, the way
     // an LZ77 copier wants it (Deflate.hs:106-120 runInflate alternates exactly these two actions): a run of literal bytes
@@ -2063,7 +2063,9 @@ struct Decoder {
 #define PZG_STRIP_BACK 768
 #endif
     static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may decode per span (a multiple of 16)
-    static_assert(STRIP_TMAX % 16u == 0u && STRIP_TMAX <= 4096u, "region geometry");
+    // (a strip of C <= STRIP_TMAX x the shortest code bits holds at most STRIP_TMAX tokens, so at most as many records and literal
+    // bytes: a region cannot overflow, and a run of literals inside one strip cannot outgrow the record's eight-bit count)
+    static_assert(STRIP_TMAX % 16u == 0u && STRIP_TMAX <= 240u, "region geometry; a record counts up to 255 literals");
 #ifndef PZG_SEQ_GROUP
 #define PZG_SEQ_GROUP 8
 #endif
@@ -2089,7 +2091,7 @@ struct Decoder {
     PZG_FN static constexpr uint32_t reg_lit(uint32_t k) { return k * REG_BYTES + REG_LITA; }             // byte offset of its first literal
 
     // A sequence record:  [14:0] distance - 1   [22:15] match length - 3   [30:23] literals in front of the match (0..255)
-    //                     [31] no match follows (the literal run was cut at 255, or the lane's strip ended in literals)
+    //                     [31] no match follows (the lane's strip ended in literals)
     static constexpr uint32_t SEQ_NOMATCH = 0x80000000u;
     PZG_FN static uint32_t seq_nl(uint32_t rec) { return (rec >> 23) & 255u; }
     PZG_FN static uint32_t seq_len(uint32_t rec) { return (int32_t)rec < 0 ? 0u : ((rec >> 15) & 255u) + 3u; }
@@ -2302,7 +2304,7 @@ struct Decoder {
     }
     // what a lane of phase B has produced so far
     struct SeqOut {
-        LaneVec<uint32_t> N, STF;        // tokens decoded; 1 = met a stopper, 2 = region full
+        LaneVec<uint32_t> STF;           // 1 = met a stopper
         LaneVec<uint32_t> NR, NLB, LR;   // records / literal bytes produced; literals since the last record
         LaneVec<uint32_t> REC[SEQ_G];    // the last records, REC[SEQ_G - 1] the newest
         LaneVec<uint32_t> LA[4];         // the last 16 literal bytes, the newest in the top byte of LA[3]
@@ -2334,11 +2336,10 @@ struct Decoder {
             strip_merge(PZG_LV(T, k), PZG_LV(PD, k), PZG_SR(L0), PZG_SR(L1));
             uint32_t tb, tk;
             strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk);
-            const bool act = PZG_LV(ACT, k), full = PZG_LV(o.N, k) >= STRIP_TMAX, stop = tb >= 128u;
-            const bool ok = act & !stop & !full;
-            PZG_LV(o.STF, k) = (act & stop) ? 1u : (act & full) ? 2u : PZG_LV(o.STF, k);
+            const bool act = PZG_LV(ACT, k), stop = tb >= 128u;
+            const bool ok = act & !stop;
+            PZG_LV(o.STF, k) = (act & stop) ? 1u : PZG_LV(o.STF, k);
             const bool is_m = ok & ((int32_t)tk < 0), is_l = ok & ((int32_t)tk >= 0);
-            PZG_LV(o.N, k) += ok ? 1u : 0u;
             // a literal: its byte enters the 16-byte accumulator from the top (a funnel shift by 8 or by nothing: no selects)
             const uint32_t sh = is_l ? 8u : 0u;
             PZG_LV(o.LA[0], k) = funnel(PZG_LV(o.LA[1], k), PZG_LV(o.LA[0], k), sh);
@@ -2347,11 +2348,10 @@ struct Decoder {
             PZG_LV(o.LA[3], k) = funnel(tk >> 8, PZG_LV(o.LA[3], k), sh);
             const uint32_t nlb = PZG_LV(o.NLB, k) + (is_l ? 1u : 0u), lr = PZG_LV(o.LR, k) + (is_l ? 1u : 0u);
             PZG_LV(o.NLB, k) = nlb;
-            // a record: a match closes the sequence its literals opened; a run of 255 literals is cut
-            const bool emit = is_m | (is_l & (lr == 255u));
+            // a record: a match closes the sequence its literals opened
+            const bool emit = is_m;
             const uint32_t a = tk - 0x00030001u;  // (length - 3) << 16 | distance - 1: no borrow (distance >= 1)
-            const uint32_t mrec = (a & 0x7fffu) | (((a >> 16) & 0xffu) << 15) | (lr << 23);
-            const uint32_t rec = is_m ? mrec : (SEQ_NOMATCH | (255u << 23));
+            const uint32_t rec = (a & 0x7fffu) | (((a >> 16) & 0xffu) << 15) | (lr << 23);
 #pragma unroll
             for (uint32_t g = 0; g + 1u < SEQ_G; ++g) PZG_LV(o.REC[g], k) = emit ? PZG_LV(o.REC[g + 1u], k) : PZG_LV(o.REC[g], k);
             PZG_LV(o.REC[SEQ_G - 1u], k) = emit ? rec : PZG_LV(o.REC[SEQ_G - 1u], k);
@@ -2458,7 +2458,6 @@ struct Decoder {
         PZG_LANES_BEGIN(k)
             PZG_LV(S, k) = PZG_LV(P, k);
             PZG_LV(LIM, k) += C;
-            PZG_LV(o.N, k) = 0u;
             PZG_LV(o.STF, k) = 0u;
             PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
 #pragma unroll
@@ -2474,7 +2473,6 @@ struct Decoder {
                     if (lane_bit(dirty, k)) {
                         const uint32_t p = PZG_LV(S, k);
                         PZG_LV(P, k) = p;
-                        PZG_LV(o.N, k) = 0u;
                         PZG_LV(o.STF, k) = 0u;
                         PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
                         strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
