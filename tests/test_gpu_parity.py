@@ -147,6 +147,87 @@ def test_strips_valid_and_corrupt_vs_oracle(ctx, oracle):
             assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())
 
 
+def _check_against_oracle(oracle, streams, caps, res, outs, datas=None):
+    import pure_zlib_amd.zlib as Z
+    out_len, status, detail, in_used, adler = res
+    for k in range(len(streams)):
+        r, o = oracle.decompress(streams[k], caps[k])
+        assert status[k] == r.status, (k, status[k], r.status, r.message.decode())
+        if r.status == 0:
+            assert outs[k] == o and int(adler[k]) == r.adler and int(in_used[k]) == r.in_used and int(out_len[k]) == r.out_len, k
+            assert datas is None or datas[k] is None or o == datas[k], k
+        elif r.status == 14:
+            assert int(out_len[k]) == r.out_len
+        else:
+            err = Z.error_from_status(streams[k], int(status[k]), detail[k])
+            assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())
+
+
+def test_exotic_streams_vs_oracle(ctx, oracle):
+    """Round 5: the strips and the groups had only ever met what zlib's encoder writes.  96 streams from
+    tests/deflate_writer.py -- a DEFLATE writer that emits chosen tokens with chosen code lengths: 13-15-bit literal/length and
+    distance codes in blocks long enough for spans, incomplete codes, a single distance code, code 16 first, code-length runs past
+    HLIT + HDIST, HLIT 288 / HDIST 32, matches of 258 bytes and of distance 32768, distance-1 runs, hundreds of tiny dynamic blocks
+    at odd bit offsets, fixed / stored / dynamic interleaved (the system zlib rejects nearly all of them; the reference accepts them:
+    Deflate.hs:124-156, HuffmanTree.hs:43-83) -- and five corrupted variants of each: 576 streams in ONE launch per ring, against
+    the oracle: status, message, in_used, Adler-32, every byte."""
+    import deflate_writer as W
+    streams, caps, datas = [], [], []
+    for seed in range(96):
+        d, z, _ = W.exotic_stream(seed)
+        streams.append(z)
+        caps.append(len(d))
+        datas.append(d)
+        for c in range(5):
+            streams.append(corpus.corrupt(z, seed * 16 + c))
+            caps.append([len(d) + 64, len(d) // 2, len(d)][c % 3])
+            datas.append(None)
+    res, outs, _, _ = run_batch(ctx, streams, caps)
+    _check_against_oracle(oracle, streams, caps, res, outs, datas)
+
+
+def test_strips_with_failing_guesses_on_the_device(tmp_path):
+    """the "guesses keep failing" path of the strips (spans that end after a strip or two, `poor`, the rest
+    of the block left to the windows; repaired lanes re-storing their regions) had only run on the one-lane host model, which
+    cannot see a cross-lane ordering bug.  build/lab_poor/libpzg.so is the product's source with the run-up cut to 8 bits and two
+    rounds of phase B (tests/tools/lab_build.sh; built by tests/test_exotic_streams.py on the CPU side): zlib-made and writer-made
+    streams, valid and corrupted, rings 11 and 15, against the oracle -- in a child process (PZG_LIB)."""
+    import sys
+    from test_exotic_streams import POOR_FLAGS, lab_library
+    so = lab_library("poor", POOR_FLAGS)
+    code = r'''
+import os, sys, zlib
+sys.path.insert(0, os.path.join(os.environ["PZG_ROOT"], "tests")); sys.path.insert(0, os.environ["PZG_ROOT"])
+import torch; torch.cuda.init()
+import corpus, deflate_writer as W
+import pure_zlib_amd as P
+from pure_zlib_amd import _ffi
+from oracle import oracle as O
+assert _ffi.LIB_PATH.endswith("build/lab_poor/libpzg.so"), _ffi.LIB_PATH
+ctx = P.Context(0)
+streams = []
+for seed in range(40):
+    z = W.exotic_stream(seed)[1] if seed % 2 else corpus.strip_case(seed)[1]
+    streams.append(z)
+    for c in range(3):
+        streams.append(corpus.corrupt(z, seed * 16 + c))
+for ring in (11, 15):
+    ctx.set_ring_bits(ring)
+    got = P.decompress_many(streams, ctx=ctx)
+    for k, (z, g) in enumerate(zip(streams, got)):
+        r, o = O.decompress(z, 1 << 21)
+        if r.status == 0:
+            assert g == P.Right(o), (ring, k)
+        else:
+            assert (not g.is_right()) and g.value.show() == r.message.decode(), (ring, k, g, r.message)
+ctx.close()
+print("poor strips parity ok", len(streams))
+'''
+    env = dict(os.environ, PZG_LIB=so, PZG_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "poor strips parity ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_text_blobs_with_far_back_references(ctx, oracle):
     """32-100 KiB Zipf text: distances up to 32 KiB, i.e. older than every hybrid ring."""
     streams, datas = [], []
