@@ -121,8 +121,10 @@ extern "C" {
                               * staging, no copy-out; this is the path the module mirrors (`decompress` / `decompressMany`) take.
                               * Requirements: extents in ascending order on both sides (in_off[i] + in_len[i] <= in_off[i+1], the same for
                               * out_off / out_cap; PZG_RC_BAD_ARG otherwise); the whole span of the output arena from the first extent
-                              * to the end of the last is written (bytes in gaps BETWEEN extents are unspecified afterwards, bytes
-                              * outside the span are untouched); gaps of the input arena travel over the link, so pack tightly
+                              * to the end of the last is written (bytes in gaps BETWEEN extents, and the bytes of an extent past its
+                              * stream's out_len[i] -- a stream that failed or came out short -- are unspecified afterwards: they may
+                              * hold what an earlier batch of this context decoded; bytes outside the span are untouched.  The staged
+                              * path, without this flag, writes out_len[i] bytes per extent and nothing else); gaps of the input arena travel over the link, so pack tightly
                               * (16-byte aligned extents keep the wide store path).  Pageable memory under this flag is still
                               * correct, only slower.  Not combined with preset dictionaries. */
 
@@ -130,10 +132,11 @@ typedef struct pzg_ctx pzg_ctx;
 
 /* Create a context on HIP device `device` (0-based).  One HIP stream + grow-only device
  * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device.
- * Device memory the library takes for itself, grow-only until pzg_shutdown: the kernels' token scratch -- 52.5 KiB per stream-wave
- * of a launch (one wave per stream, at most the residency of the chip: 6,656 waves = 341 MiB on an MI355X), two such arenas per
- * device for PZG_DEVICE_PTRS launches and one per host-path pipeline in use -- beside the host path's staging arenas.  A launch
- * whose scratch cannot be allocated still decodes, by the slower window path alone. */
+ * Device memory the library takes for itself, grow-only until pzg_shutdown: the kernels' scratch -- 64.5 KiB per stream-wave
+ * of a launch (one wave per stream, at most the residency of the chip: 6,656 waves = 419 MiB on an MI355X), two such arenas per
+ * device for PZG_DEVICE_PTRS launches and one per host-path pipeline in use (four at the most: 2.5 GiB per device in the worst
+ * case; PZG_OPT_SCRATCH_BYTES bounds it) -- beside the host path's staging arenas.  A launch whose scratch cannot be allocated,
+ * or only in part, still decodes: the stream-waves without a slice take the slower path that needs none. */
 PZG_API int  pzg_init(int device, pzg_ctx **out);
 /* decompressMany over SEVERAL devices of one node (API of Zlib.hs:32-35, batched): bit d of `device_mask`
  * selects HIP device d, 0 selects every visible device.  One call of pzg_decompress_many() with HOST pointers then
@@ -170,6 +173,14 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
 /* PZG_OPT_HOST_THREADS: helper threads (1..256) that pack / copy out the STAGED host-pointer path and the decoders' feeds
  *   (default: the machine's hardware threads, at most 24).  Set it while no host-pointer call is running. */
 #define PZG_OPT_HOST_THREADS 2
+/* PZG_OPT_SCRATCH_BYTES: upper bound, per device, on the scratch memory the LIBRARY allocates for its inflate kernels (0, the
+ *   default: no bound).  A launch's stream-waves decode long runs of input through a scratch of 64.5 KiB each -- 419 MiB for a
+ *   launch that fills an MI355X (6,656 stream-waves) -- and a context keeps up to six such arenas per device, grow-only: two for
+ *   device-pointer launches (overlapping launches must not share one) and one per host-path pipeline (four), 2.5 GiB at the
+ *   most.  With a bound every arena gets an even share (bound / 6): only as many stream-waves as fit own a slice, the others
+ *   decode by the slower path that needs no scratch; below 64.5 KiB per arena all of them do.  Results never depend on it.
+ *   Takes effect launch by launch (an arena larger than its share is released when it is next used). */
+#define PZG_OPT_SCRATCH_BYTES 3
 PZG_API int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
 /* The only environment variable the library reads is PZG_RING_BITS (11..15): the default of PZG_OPT_RING_BITS for
  * contexts created afterwards. */
@@ -189,7 +200,8 @@ PZG_API void  pzg_host_free(void *p);
  *   status[n]              PZG_OK or PZG_E_*
  *   detail[2n]             two detail words per stream (see the status table); may be NULL
  *   in_used[n]             input bytes consumed incl. the Adler trailer; may be NULL
- *   adler[n]               Adler-32 computed over the decoded bytes; may be NULL
+ *   adler[n]               Adler-32 computed over the decoded bytes; may be NULL.  (Of a stream that failed: over what had been
+ *                          decoded by then -- 0 if it had outgrown out_cap[i] by then: what lies past the capacity is not stored.)
  *
  * Extents may be laid out with gaps (aligned arenas) and in any order; they must not overlap on the
  * output side.  One compressed stream may be up to 16 GiB (longer ones report PZG_E_TRUNCATED); the decoded size is

@@ -40,6 +40,7 @@ LPT_ORDER = 8  # device-pointer batches: launch the longest streams first
 HOST_PINNED = 16  # host-pointer batches in page-locked arenas (pzg_host_alloc), extents ascending: no staging, no copy-out
 OPT_RING_BITS = 1
 OPT_HOST_THREADS = 2
+OPT_SCRATCH_BYTES = 3
 DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares

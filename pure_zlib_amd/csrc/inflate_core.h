@@ -899,10 +899,14 @@ struct Decoder {
         const bool overlap = dist < len;
 #if PZG_DEVICE_PASS
         const float rd = overlap ? __builtin_amdgcn_rcpf((float)dist) : 0.0f;
+        uint32_t lane_o = lane;
+        asm volatile("" : "+v"(lane_o));  // (opaque: or lane + 64 c + 0.5 of every chunk is computed once per kernel and kept, or spilled)
+#else
+        const uint32_t lane_o = lane;
 #endif
 #pragma unroll
         for (uint32_t c = 0; c < MAXCH; ++c) {
-            const uint32_t k = c * PZG_WAVE + lane;
+            const uint32_t k = c * PZG_WAVE + lane_o;
             if (c * PZG_WAVE < len) {  // wave-uniform
                 uint32_t off = k;
                 if (overlap) {
@@ -2426,6 +2430,7 @@ struct Decoder {
             if (se) return se;
         }
         complete_pending();  // (... and the far bytes of the last segment: the groups read the ring)
+        strip_kill_window_state();
         const uint64_t pos0 = br.pos();
         const uint32_t r0 = (uint32_t)pos0 & 31u;
         const uint32_t dw0 = (uint32_t)(pos0 >> 5);
@@ -2550,7 +2555,18 @@ struct Decoder {
             if (se) return se;
         }
         PZG_HOT_ACC(11, tse);
+        strip_kill_window_state();
         return ST_OK;
+    }
+    // The windows' per-lane state holds nothing while a span runs (the queue is empty, no far byte is pending): saying so --
+    // zeros in, zeros out -- frees its vector registers for the span instead of keeping four of them alive across it.
+    PZG_FN void strip_kill_window_state()
+    {
+        PZG_LANES_BEGIN(j)
+            PZG_LV(QT, j) = 0u;
+            PZG_LV(pendF0, j) = 0;
+            PZG_LV(pendF1, j) = 0;
+        PZG_LANES_END
     }
 #undef PZG_SR
 
@@ -3082,7 +3098,10 @@ struct Decoder {
     // op + run - RING).  Every source byte lies in front of the match: for dist < len the pattern repeats with period dist.
     PZG_FN void seq_coop(uint32_t op32, uint32_t m, uint32_t dist, uint32_t len, uint32_t run)
     {
-        const uint32_t lane = lane_id();
+        uint32_t lane = lane_id();
+#if PZG_DEVICE_PASS
+        asm volatile("" : "+v"(lane));  // (opaque: or the chunks' lane + 64 c + 0.5 are computed once in front of the groups' loop and kept -- spilled -- for its whole life)
+#endif
         const uint32_t dst0 = op32 + m, src0 = dst0 - dist;
         const uint32_t fdelta = (uint32_t)(op - flushed);
         constexpr uint32_t MAXCH = (258u + PZG_WAVE - 1u) / PZG_WAVE;
@@ -3544,7 +3563,10 @@ struct Decoder {
         res->status = status;
         res->detail0 = detail0;
         res->detail1 = detail1;
-        res->adler = (adler_b << 16) | adler_a;
+        // (a stream that FAILED after it had outgrown its capacity: what lies past the capacity was never stored, on the small rings
+        // the far reads of it were skipped, so the running checksum means nothing -- and must not depend on what the wave decoded before)
+        const bool unstored = op > cap && status != ST_OK && status != ST_OUT_TOO_SMALL && status != ST_RETRY_FULL_RING;
+        res->adler = unstored ? 0u : (adler_b << 16) | adler_a;
         res->gz_crc = gz_expect;
         res->out_len = op;
         res->in_used = used;

@@ -38,6 +38,36 @@
 
 namespace {
 
+// A helper thread of one call that is joined whatever way the call ends (a std::thread destroyed while joinable ends
+// the process): `wake` makes the thread's loop end -- it sets the call's stop flags under the call's mutex and notifies -- and
+// runs first when the guard dies while the thread is still running (an early return, an exception on the issuing thread).
+// start() returns false when the system has no thread to give: the caller then runs the stage inline.
+struct CallThread {
+    std::thread t;
+    std::function<void()> wake;
+    template <class F>
+    bool start(F &&body)
+    {
+        try {
+            t = std::thread(std::forward<F>(body));
+            return true;
+        } catch (const std::system_error &) {
+            return false;
+        }
+    }
+    void join()
+    {
+        if (t.joinable()) t.join();
+    }
+    ~CallThread()
+    {
+        if (t.joinable()) {
+            if (wake) wake();
+            t.join();
+        }
+    }
+};
+
 struct Arena {
     void *p = nullptr;
     size_t cap = 0;
@@ -107,6 +137,7 @@ struct pzg_ctx {
     std::string last_error;
     void *prof_buf = nullptr;  // diagnostic builds only
     std::unique_ptr<Helpers> helpers;
+    std::atomic<uint64_t> scratch_cap{0};  // PZG_OPT_SCRATCH_BYTES: the kernels' scratch per device, at most (0: no limit)
 };
 
 namespace {
@@ -143,6 +174,44 @@ int arena_reserve(pzg_ctx *ctx, Arena &a, size_t bytes)
     }
     a.cap = bytes;
     return PZG_RC_OK;
+}
+
+// The kernels' scratch for one launch of n streams into arena `a`: as many whole stream-wave slices as the launch can use and the
+// context's cap (PZG_OPT_SCRATCH_BYTES, shared evenly by the arenas a shard can hold) allows.  Failing is tolerated -- the
+// launch then decodes by windows alone, slower and never wrong -- so nothing is recorded as an error.
+void strip_for_launch(pzg_ctx *ctx, Arena &a, int num_cus, uint32_t n, uint32_t gzip, pzg::InflateArgs &args);
+
+void strip_for_launch(pzg_ctx *ctx, Arena &a, int num_cus, uint32_t n, uint32_t gzip, pzg::InflateArgs &args)
+{
+    args.strip = nullptr;
+    args.strip_waves = 0;
+    const size_t per_wave = pzg::inflate_strip_wave_bytes();
+    size_t want = pzg::inflate_strip_bytes(ctx->ring_bits, num_cus, n, gzip);
+    const uint64_t cap = ctx->scratch_cap.load();
+    if (cap != 0) {  // a shard holds STRIP_SLOTS arenas for device-pointer launches and one per host-path lane: an even share each
+        const size_t share = (size_t)(cap / (uint64_t)(STRIP_SLOTS + LANES_PER_SHARD)) / per_wave * per_wave;
+        if (want > share) want = share;
+        if (a.cap > share + 255u) {  // (held from before the cap was set: given back)
+            (void)hipFree(a.p);
+            a.p = nullptr;
+            a.cap = 0;
+        }
+    }
+    if (want < per_wave) return;
+    if (a.cap < want) {
+        if (a.p) (void)hipFree(a.p);
+        a.p = nullptr;
+        a.cap = 0;
+        void *q = nullptr;
+        if (hipMalloc(&q, (want + 255u) & ~(size_t)255u) != hipSuccess) {
+            (void)hipGetLastError();  // (tolerated: the launch decodes by windows alone)
+            return;
+        }
+        a.p = q;
+        a.cap = (want + 255u) & ~(size_t)255u;
+    }
+    args.strip = (uint32_t *)a.p;
+    args.strip_waves = (uint32_t)(want / per_wave);
 }
 
 void pinned_release(Pinned &a)
@@ -334,8 +403,7 @@ int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
     // the kernels then decode by windows alone -- slower, never wrong)
     const uint32_t ss = sh.next_strip++ % STRIP_SLOTS;
     if (sh.strip_used[ss]) HIP_TRY(ctx, hipStreamWaitEvent(sh.stream, sh.ev_strip[ss], 0));
-    if (arena_reserve(ctx, sh.a_strip[ss], pzg::inflate_strip_bytes(ctx->ring_bits, sh.num_cus, a.n, a.gzip)) == PZG_RC_OK)
-        a.strip = (uint32_t *)sh.a_strip[ss].p;
+    strip_for_launch(ctx, sh.a_strip[ss], sh.num_cus, a.n, a.gzip, a);
 #if defined(PZG_LAB)  // lab builds only: the windows alone
     if (getenv("PZG_NO_STRIPS")) a.strip = nullptr;
 #endif
@@ -488,9 +556,8 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         if ((b.flags & PZG_GZIP) && (rc = arena_reserve(ctx, ln.d_gz[s], 8 * max_n + 64)) != PZG_RC_OK) return rc;
         if ((rc = pinned_reserve(ctx, ln.h_meta[s], meta_bytes + 64)) != PZG_RC_OK) return rc;
     }
-    uint32_t *d_strip = nullptr;  // (all launches of the call go to s_k, one after the other: one scratch)
-    if (arena_reserve(ctx, ln.d_strip, pzg::inflate_strip_bytes(ctx->ring_bits, sh.num_cus, (uint32_t)max_n, (b.flags & PZG_GZIP) ? 1u : 0u)) == PZG_RC_OK)
-        d_strip = (uint32_t *)ln.d_strip.p;
+    pzg::InflateArgs strip_args{};  // (all launches of the call go to s_k, one after the other: one scratch)
+    strip_for_launch(ctx, ln.d_strip, sh.num_cus, (uint32_t)max_n, (b.flags & PZG_GZIP) ? 1u : 0u, strip_args);
     const unsigned helpers = (!pinned && (tot_in + tot_out) >= (32ull << 20)) ? ctx->helpers->size() : 1u;
 
     auto meta_ptrs = [&](uint8_t *base, size_t nn, uint64_t *&ioff, uint64_t *&ilen, uint64_t *&ooff, uint64_t *&ocap, uint64_t *&olen,
@@ -592,6 +659,29 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
     size_t issued = 0, unpacked = 0;  // ranges issued / handed back so far
     bool abort_drain = false;
     hipError_t derr = hipSuccess;
+    // one range handed back: wait for its download, copy it out (a std::bad_alloc of the helpers' job list is reported, not thrown
+    // across a thread boundary)
+    auto drain_one = [&](size_t c) {
+        const int s = (int)(c % nslot);
+        auto tw = tick();
+        hipError_t e = hipEventSynchronize(ln.ev_dn[s]);
+        t_wait += since(tw);
+        auto tu = tick();
+        if (e == hipSuccess) {
+            try {
+                unpack(rg[c], s);
+            } catch (...) {
+                e = hipErrorOutOfMemory;
+            }
+        }
+        t_unpack += since(tu);
+        {
+            std::lock_guard<std::mutex> g(pm);
+            if (e != hipSuccess && derr == hipSuccess) derr = e;
+            unpacked = c + 1;
+        }
+        pcv.notify_all();
+    };
     auto drain = [&] {
         (void)hipSetDevice(sh.device);
         for (size_t c = 0; c < R; ++c) {
@@ -600,28 +690,26 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
                 pcv.wait(g, [&] { return issued > c || abort_drain; });
                 if (abort_drain && issued <= c) return;
             }
-            const int s = (int)(c % nslot);
-            auto tw = tick();
-            const hipError_t e = hipEventSynchronize(ln.ev_dn[s]);
-            t_wait += since(tw);
-            auto tu = tick();
-            if (e == hipSuccess) unpack(rg[c], s);
-            t_unpack += since(tu);
-            {
-                std::lock_guard<std::mutex> g(pm);
-                if (e != hipSuccess && derr == hipSuccess) derr = e;
-                unpacked = c + 1;
-            }
-            pcv.notify_all();
+            drain_one(c);
         }
     };
-    std::thread drainer;
-    if (R > 1) drainer = std::thread(drain);
+    CallThread drainer;
+    drainer.wake = [&] {
+        {
+            std::lock_guard<std::mutex> g(pm);
+            abort_drain = true;
+        }
+        pcv.notify_all();
+    };
+    const bool threaded = R > 1 && drainer.start(drain);  // (no thread to be had: this thread hands the ranges back itself)
+    size_t drained_inline = 0;
     for (size_t c = 0; c < R && herr == hipSuccess; ++c) {
         const Range &r = rg[c];
         const int s = (int)(c % nslot);
         const size_t nn = r.hi - r.lo;
         if (c >= (size_t)nslot) {  // the slot's previous occupant (range c - nslot) must have left the pinned buffers
+            if (!threaded)
+                while (drained_inline + nslot <= c) drain_one(drained_inline++);
             std::unique_lock<std::mutex> g(pm);
             pcv.wait(g, [&] { return unpacked + nslot > c; });
             if (derr != hipSuccess) {
@@ -662,7 +750,8 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
         a.detail = det;
         a.n = (uint32_t)nn;
         a.counter = ln.d_counter;
-        a.strip = d_strip;
+        a.strip = strip_args.strip;
+        a.strip_waves = strip_args.strip_waves;
         if (b.flags & PZG_GZIP) {
             a.gzip = 1;
             a.gz_expect = (uint32_t *)ln.d_gz[s].p;
@@ -696,23 +785,15 @@ int host_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint32_t *idx, 
             pcv.notify_all();
         }
     }
-    if (R > 1) {
-        {
-            std::lock_guard<std::mutex> g(pm);
-            abort_drain = true;  // (a no-op when every range was issued: the drainer finishes them all first)
-        }
-        pcv.notify_all();
+    if (threaded) {
+        drainer.wake();  // (a no-op when every range was issued: the drainer finishes them all first)
         drainer.join();
-        if (herr == hipSuccess && derr != hipSuccess) {
-            herr = derr;
-            hwhat = "hipEventSynchronize (download)";
-        }
     } else if (herr == hipSuccess) {
-        drain();
-        if (derr != hipSuccess) {
-            herr = derr;
-            hwhat = "hipEventSynchronize (download)";
-        }
+        while (drained_inline < R) drain_one(drained_inline++);
+    }
+    if (herr == hipSuccess && derr != hipSuccess) {
+        herr = derr;
+        hwhat = derr == hipErrorOutOfMemory ? "copy-out of a range (out of memory)" : "hipEventSynchronize (download)";
     }
 #undef LANE_TRY
     if (herr != hipSuccess) {
@@ -788,7 +869,7 @@ int dict_path(pzg_ctx *ctx, Shard &sh, const HostBatch &b, const uint8_t *dict_b
     a.detail = a.adler + n;
     a.n = n;
     a.counter = ln.d_counter;
-    if (arena_reserve(ctx, ln.d_strip, pzg::inflate_strip_bytes(ctx->ring_bits, sh.num_cus, n, 0u)) == PZG_RC_OK) a.strip = (uint32_t *)ln.d_strip.p;
+    strip_for_launch(ctx, ln.d_strip, sh.num_cus, n, 0u, a);
     HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, st));
     std::vector<uint8_t> res(32 * (size_t)n), hout(op + 16);
     HIP_TRY(ctx, hipMemcpyAsync(res.data(), dm + 48 * (size_t)n, 32 * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -948,6 +1029,10 @@ int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
     if (!ctx_live(ctx)) return PZG_RC_BAD_ARG;
     if (option == PZG_OPT_RING_BITS && value >= 11 && value <= 15) {
         ctx->ring_bits = (int)value;
+        return PZG_RC_OK;
+    }
+    if (option == PZG_OPT_SCRATCH_BYTES && value >= 0) {  // (takes effect launch by launch: an arena larger than its share is given back when next used)
+        ctx->scratch_cap.store((uint64_t)value);
         return PZG_RC_OK;
     }
     if (option == PZG_OPT_HOST_THREADS && value >= 1 && value <= 256) {  // (not while host-pointer calls are running)
@@ -1448,44 +1533,93 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
             auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
             double t_pack = 0, t_res = 0, t_dat = 0, t_out = 0;
 #endif
-            // the third thread: hands a fetched range to the caller (results into the caller's arrays, bytes out of the staging)
-            std::thread copier([&] {
+            // one fetched range handed to the caller (results into the caller's arrays, bytes out of the staging)
+            auto copy_one = [&](uint32_t c) {
+                const uint32_t j0 = lo[c], j1 = lo[c + 1];
+                if (j0 == j1) return;
+#if defined(PZG_LAB)
+                const auto t0 = std::chrono::steady_clock::now();
+#endif
+                uint64_t delivered = 0;
+                for (uint32_t j = j0; j < j1; ++j) {
+                    out_len[j] = olen[j];
+                    state[j] = stt[j];
+                    in_used[j] = used[j];
+                    chunks[j] = ch[j];
+                    if (adler) adler[j] = ad[j];
+                    if (detail) {
+                        detail[2 * (size_t)j] = det[2 * (size_t)j];
+                        detail[2 * (size_t)j + 1] = det[2 * (size_t)j + 1];
+                    }
+                    delivered += olen[j] <= ocap[j] ? olen[j] : ocap[j];
+                }
+                const uint32_t nn = j1 - j0;
+                ctx->helpers->run(delivered >= (4u << 20) ? (ctx->helpers->size() + 1u) / 2u : 1u, [&](unsigned part, unsigned nparts) {
+                    for (uint32_t j = j0 + (uint32_t)((uint64_t)nn * part / nparts), e2 = j0 + (uint32_t)((uint64_t)nn * (part + 1) / nparts); j < e2; ++j)
+                        if (olen[j]) memcpy(out_base + out_off[j], hout + doff[j], olen[j] <= ocap[j] ? olen[j] : ocap[j]);
+                });
+#if defined(PZG_LAB)
+                t_out += ms_since(t0);
+#endif
+            };
+            // one issued range fetched: wait for its results, bring down what its decoders delivered
+            auto fetch_one = [&](uint32_t c) -> hipError_t {
+                const uint32_t j0 = lo[c], j1 = lo[c + 1];
+                if (j0 == j1) return hipSuccess;
+#if defined(PZG_LAB)
+                auto t0 = std::chrono::steady_clock::now();
+#endif
+                hipError_t e = hipEventSynchronize(dec->ev_res[c]);
+#if defined(PZG_LAB)
+                t_res += ms_since(t0);
+                t0 = std::chrono::steady_clock::now();
+#endif
+                uint64_t delivered = 0;  // the decoders of the range packed their bytes behind one another from ooff[j0] on (whole 16-byte vectors each)
+                for (uint32_t j = j0; j < j1 && e == hipSuccess; ++j) delivered += pad16(olen[j]);
+                if (e == hipSuccess && delivered != 0) {
+                    e = hipMemcpyAsync(hout + ooff[j0], (const uint8_t *)dec->d_dense.p + ooff[j0], delivered, hipMemcpyDeviceToHost, dec->s_dat);
+                    if (e == hipSuccess) e = hipStreamSynchronize(dec->s_dat);
+                }
+#if defined(PZG_LAB)
+                t_dat += ms_since(t0);
+#endif
+                return e;
+            };
+            // The second and third thread of the call (joined whatever way the call ends; an exception inside one -- the helpers'
+            // job list can run out of memory -- is reported through derr, never thrown across the thread boundary).  Without them
+            // (the system has no thread to give) the issuing thread fetches and copies the ranges itself once all are issued.
+            CallThread copier, drainer;
+            copier.wake = [&] {
+                {
+                    std::lock_guard<std::mutex> g(pm);
+                    stop_copy = true;
+                }
+                pcv.notify_all();
+            };
+            drainer.wake = [&] {
+                {
+                    std::lock_guard<std::mutex> g(pm);
+                    stop = true;
+                }
+                pcv.notify_all();
+            };
+            auto copier_body = [&] {
                 for (uint32_t c = 0; c < R; ++c) {
                     {
                         std::unique_lock<std::mutex> g(pm);
                         pcv.wait(g, [&] { return fetched > c || stop_copy; });
                         if (fetched <= c) return;
                     }
-                    const uint32_t j0 = lo[c], j1 = lo[c + 1];
-                    if (j0 == j1) continue;
-#if defined(PZG_LAB)
-                    const auto t0 = std::chrono::steady_clock::now();
-#endif
-                    uint64_t delivered = 0;
-                    for (uint32_t j = j0; j < j1; ++j) {
-                        out_len[j] = olen[j];
-                        state[j] = stt[j];
-                        in_used[j] = used[j];
-                        chunks[j] = ch[j];
-                        if (adler) adler[j] = ad[j];
-                        if (detail) {
-                            detail[2 * (size_t)j] = det[2 * (size_t)j];
-                            detail[2 * (size_t)j + 1] = det[2 * (size_t)j + 1];
-                        }
-                        delivered += olen[j] <= ocap[j] ? olen[j] : ocap[j];
+                    try {
+                        copy_one(c);
+                    } catch (...) {
+                        std::lock_guard<std::mutex> g(pm);
+                        if (derr == hipSuccess) derr = hipErrorOutOfMemory;
+                        return;
                     }
-                    const uint32_t nn = j1 - j0;
-                    ctx->helpers->run(delivered >= (4u << 20) ? (ctx->helpers->size() + 1u) / 2u : 1u, [&](unsigned part, unsigned nparts) {
-                        for (uint32_t j = j0 + (uint32_t)((uint64_t)nn * part / nparts), e2 = j0 + (uint32_t)((uint64_t)nn * (part + 1) / nparts); j < e2; ++j)
-                            if (olen[j]) memcpy(out_base + out_off[j], hout + doff[j], olen[j] <= ocap[j] ? olen[j] : ocap[j]);
-                    });
-#if defined(PZG_LAB)
-                    t_out += ms_since(t0);
-#endif
                 }
-            });
-            // the second thread: waits for a range's results and fetches what its decoders delivered
-            std::thread drainer([&] {
+            };
+            auto drainer_body = [&] {
                 (void)hipSetDevice(dec->device);
                 for (uint32_t c = 0; c < R; ++c) {
                     {
@@ -1493,32 +1627,7 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                         pcv.wait(g, [&] { return issued > c || stop; });
                         if (issued <= c) return;
                     }
-                    const uint32_t j0 = lo[c], j1 = lo[c + 1];
-                    if (j0 == j1) {
-                        {
-                            std::lock_guard<std::mutex> g(pm);
-                            fetched = c + 1;
-                        }
-                        pcv.notify_all();
-                        continue;
-                    }
-#if defined(PZG_LAB)
-                    auto t0 = std::chrono::steady_clock::now();
-#endif
-                    hipError_t e = hipEventSynchronize(dec->ev_res[c]);
-#if defined(PZG_LAB)
-                    t_res += ms_since(t0);
-                    t0 = std::chrono::steady_clock::now();
-#endif
-                    uint64_t delivered = 0;  // the decoders of the range packed their bytes behind one another from ooff[j0] on (whole 16-byte vectors each)
-                    for (uint32_t j = j0; j < j1 && e == hipSuccess; ++j) delivered += pad16(olen[j]);
-                    if (e == hipSuccess && delivered != 0) {
-                        e = hipMemcpyAsync(hout + ooff[j0], (const uint8_t *)dec->d_dense.p + ooff[j0], delivered, hipMemcpyDeviceToHost, dec->s_dat);
-                        if (e == hipSuccess) e = hipStreamSynchronize(dec->s_dat);
-                    }
-#if defined(PZG_LAB)
-                    t_dat += ms_since(t0);
-#endif
+                    const hipError_t e = fetch_one(c);
                     {
                         std::lock_guard<std::mutex> g(pm);
                         if (e != hipSuccess && derr == hipSuccess) derr = e;
@@ -1528,7 +1637,13 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                     pcv.notify_all();
                     if (e != hipSuccess) return;
                 }
-            });
+            };
+            bool threaded = copier.start(copier_body);
+            if (threaded && !drainer.start(drainer_body)) {
+                copier.wake();
+                copier.join();
+                threaded = false;
+            }
             for (uint32_t c = 0; c < R && herr == hipSuccess; ++c) {
                 const uint32_t j0 = lo[c], j1 = lo[c + 1];
                 if (j0 != j1) {
@@ -1576,18 +1691,17 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                 }
             }
 #undef FEED_TRY
-            {
-                std::lock_guard<std::mutex> g(pm);
-                stop = true;
+            if (threaded) {
+                drainer.wake();
+                drainer.join();
+                copier.wake();  // (a no-op when every range was fetched: the copier finishes them all first)
+                copier.join();
+            } else if (herr == hipSuccess) {
+                for (uint32_t c = 0; c < R && derr == hipSuccess; ++c) {
+                    derr = fetch_one(c);
+                    if (derr == hipSuccess) copy_one(c);  // (an exception here is the issuing thread's: the call's own catch reports it)
+                }
             }
-            pcv.notify_all();
-            drainer.join();
-            {
-                std::lock_guard<std::mutex> g(pm);
-                stop_copy = true;  // (a no-op when every range was fetched: the copier finishes them all first)
-            }
-            pcv.notify_all();
-            copier.join();
 #if defined(PZG_LAB)
             if (trace)
                 fprintf(stderr, "[pzg] feed: %u decoders, %.1f MiB in, %.1f MiB of rooms: %.1f ms (issuing thread: packing %.1f; draining thread: waiting for "

@@ -49,6 +49,13 @@ public:
         work_on(*job);
         std::unique_lock<std::mutex> g(mu_);
         done_cv_.wait(g, [&] { return job->done == job->parts; });
+        // the job leaves the queue with its caller (a worker may have taken it out already; with no worker at all -- none could
+        // be started -- nobody else ever would, and the queue would grow by one job, holding a dangling reference, per call)
+        for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
+            if (*it == job) {
+                jobs_.erase(it);
+                break;
+            }
     }
 
 private:
@@ -81,11 +88,11 @@ private:
                     for (;;) {
                         cv_.wait(g, [&] { return quit_ || !jobs_.empty(); });
                         if (quit_) return;
+                        // the first job that still has a part to take (two callers -- a pack on the issuing thread, a copy-out on
+                        // the draining one -- are served side by side; fully taken jobs in front leave the queue)
+                        while (!jobs_.empty() && jobs_.front()->next.load() >= jobs_.front()->parts) jobs_.pop_front();
+                        if (jobs_.empty()) continue;
                         std::shared_ptr<Job> j = jobs_.front();
-                        if (j->next.load() >= j->parts) {  // every part is taken: the job leaves the queue
-                            jobs_.pop_front();
-                            continue;
-                        }
                         g.unlock();
                         work_on(*j);
                         g.lock();

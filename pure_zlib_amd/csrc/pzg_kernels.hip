@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_k
             // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
             if (FIXUP && a->status[i] != ST_RETRY_FULL_RING) continue;
             Decoder<RING_BITS, GZIP> dec(lds);
-            if (!FIXUP && a->strip) dec.strip = a->strip + (size_t)blockIdx.x * Decoder<RING_BITS, GZIP>::STRIP_WORDS;
+            if (!FIXUP && a->strip && blockIdx.x < a->strip_waves) dec.strip = a->strip + (size_t)blockIdx.x * Decoder<RING_BITS, GZIP>::STRIP_WORDS;
             const uint8_t *dict = nullptr;
             uint32_t dict_len = 0;
             if (!GZIP && a->dict_len) {  // extension (PZG_FDICT): this stream's preset dictionary, if it has one
@@ -358,6 +358,7 @@ size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip
 {
     return (size_t)launch_waves(ring_bits, num_cus, n, gzip) * Decoder<11>::STRIP_WORDS * sizeof(uint32_t);
 }
+size_t inflate_strip_wave_bytes() { return (size_t)Decoder<11>::STRIP_WORDS * sizeof(uint32_t); }
 
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream)
 {

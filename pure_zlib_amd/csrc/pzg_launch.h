@@ -30,6 +30,7 @@ struct InflateArgs {
     // token scratch of the launch's stream-waves (inflate_core.h strip_span): inflate_strip_bytes() bytes, or null -- the
     // kernels then decode by windows alone.  Must not be shared with a launch that may run at the same time.
     uint32_t *strip;
+    uint32_t strip_waves;     // stream-waves (workgroups 0 .. strip_waves - 1) that own a slice of it; the others decode by windows alone
 };
 
 // one batched call of the resumable decoder (decompressIncremental): decoder i continues from its ResumeState
@@ -63,7 +64,8 @@ size_t resume_state_bytes();   // one decoder's slot: ResumeState + LDS image
 size_t resume_scalar_bytes();  // ... its ResumeState part (zeroing it makes the decoder fresh)
 
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);
-size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip);  // what InflateArgs::strip must hold for that launch
+size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip);  // what InflateArgs::strip holds when every stream-wave of that launch owns a slice
+size_t inflate_strip_wave_bytes();  // ... one stream-wave's slice
 
 // partials: 3 * 4 * ceil(max_waves / 4) uint32 of device scratch
 hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *partials, uint32_t max_waves,

@@ -197,6 +197,10 @@ class Context:
         """Helper threads of the staged host-pointer path and of the decoders' feeds (PZG_OPT_HOST_THREADS)."""
         _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_HOST_THREADS, int(n)), self._h)
 
+    def set_scratch_bytes(self, nbytes: int):
+        """Upper bound, per device, on the scratch the library allocates for its inflate kernels (PZG_OPT_SCRATCH_BYTES; 0: no bound)."""
+        _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_SCRATCH_BYTES, int(nbytes)), self._h)
+
     def sync(self):
         _ffi.check(self._L.pzg_sync(self._h), self._h)
 

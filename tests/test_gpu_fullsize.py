@@ -68,6 +68,31 @@ def test_config4_65536_level6_32k_blobs(gpu_ctx, oracle):
     gpu_ctx.set_ring_bits(11)
 
 
+def test_config4_with_the_scratch_capped_at_64_mib(gpu_ctx, oracle):
+    """PZG_OPT_SCRATCH_BYTES bounds the device memory the library takes for its kernels' scratch (419 MiB per
+    arena for a launch that fills the chip, up to six arenas per device).  With 64 MiB for the whole device (10.7 MiB per arena:
+    169 of the 6,656 stream-waves own a slice, the others decode by windows) BASELINE config 4 at full size is still bit-exact --
+    every stream, every byte, 256 sampled streams against the oracle; so is a launch with no scratch at all (a 1-byte cap), the
+    host-pointer path under the cap, and the next launch after the cap is lifted."""
+    import pure_zlib_amd as P
+    texts = [corpus.zipf_text(32768, seed) for seed in range(1024)]
+    zs = [zlib.compress(t, 6) for t in texts]
+    pick = np.random.default_rng(0xC8).integers(0, len(zs), size=65536)
+    b = DeviceBatch(texts, zs, pick)
+    try:
+        for cap in (64 << 20, 1, 0):
+            gpu_ctx.set_scratch_bytes(cap)
+            res = b.run(gpu_ctx, 11)
+            b.check_all(*res)
+            if cap:
+                b.check_sample_vs_oracle(oracle, 128 if cap > 1 else 16)
+                got = P.decompress_many(zs[:256], ctx=gpu_ctx)  # the host-pointer path (its own arena) under the cap
+                assert all(g == P.Right(t) for g, t in zip(got, texts[:256]))
+    finally:
+        gpu_ctx.set_scratch_bytes(0)
+        gpu_ctx.set_ring_bits(11)
+
+
 def test_262144_small_level6_blobs_2k(gpu_ctx, oracle):
     """4,096 distinct 2 KiB level-6 blobs, 64 replicas each, in one launch (the profile sweeps' 1 M x 2 KiB batch at a
     quarter of its size).  Small dynamic-Huffman streams end their windows at a stopper with the token queue nearly
