@@ -2867,11 +2867,7 @@ struct Decoder {
         c.norm3 = lanes_ballot(N3);
         c.slow = lanes_ballot(SLOW);
         const uint64_t coopm = lanes_ballot(COOP);
-#if defined(PZG_EXP_NOFAR)
-        const uint64_t nearm = lanes_ballot(NEAR), farm = 0ull;
-#else
         const uint64_t nearm = lanes_ballot(NEAR), farm = HYBRID ? lanes_ballot(FARL) & far_okmask : 0ull;
-#endif
         // ---- the far matches' sources: asked for.  They end SEQ_GLIM + ... bytes below `flushed` at the least (static_assert
         // above), in lines that are complete and final (see set_far_base).
         LaneVec<uint32_t> FO, FND, FX[4];
@@ -2937,12 +2933,7 @@ struct Decoder {
         PZG_MARK("g.matches");
         // ---- 2a. the matches that read nothing of this group (most of them), while the loads are on their way
         uint64_t pend = nearm;
-#if defined(PZG_EXP_NOCOPY)
-        pend = 0ull;
-        if (false) {
-#else
         if (nearm != 0ull) {
-#endif
             LaneVec<bool> RDY;
             PZG_LANES_BEGIN(j)
                 PZG_LV(RDY, j) = (int32_t)PZG_LV(SEND, j) <= 0;
@@ -3067,9 +3058,6 @@ struct Decoder {
         PZG_MARK("g.rounds");
         // ---- 3. matches that read this group's own bytes: the first one still waiting can always go, and with it every one
         // whose source ends in front of it
-#if defined(PZG_EXP_NOROUNDS)
-        pend = 0ull;
-#endif
         while (pend != 0ull) {
             const uint32_t first = ctz64(pend);
             const uint32_t h = lane_get(MO, first);
