@@ -38,24 +38,43 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def kernel_sha256():
+    """What the measured traffic belongs to: the kernels' source (profiles/traffic.json records it with every entry)."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("inflate_core.h", "pzg_kernels.hip", "wave.h"):
+        with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def traffic_from_profiles(args, ring_bits, n):
     """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, counters only) of
-    this same command on the committed kernel; recorded in profiles/traffic.json after each profiling session
-    (tests/tools/r4_profiles.sh).  Returns (bytes or None, where the number comes from)."""
+    this same command, recorded in profiles/traffic.json after each profiling session (tests/tools/traffic_passes.sh) together
+    with the SHA-256 of the kernels' source and the pool size of the run.  Returns (bytes or None, where the number comes
+    from -- or WHY there is none: an entry measured on other kernel source, or with another pool, is not this kernel's traffic)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        for e in t["entries"]:
-            if e["workload"] == args.workload and e["ring_bits"] == ring_bits and e["streams"] == n and bool(e.get("gzip")) == bool(args.gzip):
-                src = {"file": e.get("file", t.get("source")), "counters": "FETCH_SIZE + WRITE_SIZE (TCC_EA0_RDREQ / WRREQ based), one rocprofv3 --pmc pass each",
-                       "fetch_bytes": e["fetch_bytes"], "write_bytes": e["write_bytes"],
-                       "fetch_correction": e.get("fetch_correction", "raw (byte-granular far-window gathers dominate the reads; the x2 of the guide applies "
-                                                                     "to 16 B/lane streaming reads only)"),
-                       "kernel_revision": e.get("kernel_revision"), **({"note": e["note"]} if e.get("note") else {})}
-                return e["hbm_bytes_per_launch"], src
-    except Exception:
-        pass
-    return None, None
+    except Exception as e:
+        return None, {"reason": f"profiles/traffic.json: {e}"}
+    sha = kernel_sha256()
+    why = "no entry for this workload / ring / stream count"
+    for e in t["entries"]:
+        if e["workload"] == args.workload and e["ring_bits"] == ring_bits and e["streams"] == n and bool(e.get("gzip")) == bool(args.gzip):
+            if e.get("kernel_sha256") != sha:
+                why = f"the entry was measured on other kernel source (sha256 {str(e.get('kernel_sha256'))[:12]}..., this build {sha[:12]}...): re-run tests/tools/traffic_passes.sh"
+                continue
+            if e.get("pool") not in (None, args.pool):
+                why = f"the entry was measured with --pool {e.get('pool')}, this run uses {args.pool}"
+                continue
+            src = {"file": e.get("file", t.get("source")), "counters": "FETCH_SIZE + WRITE_SIZE (TCC_EA0_RDREQ / WRREQ based), one rocprofv3 --pmc pass each",
+                   "fetch_bytes": e["fetch_bytes"], "write_bytes": e["write_bytes"],
+                   "fetch_correction": e.get("fetch_correction", "raw (dword and byte requests at the lanes' own addresses dominate the reads; the x2 of the guide applies "
+                                                                 "to 16 B/lane streaming reads only)"),
+                   "kernel_sha256": sha, "pool": e.get("pool"), **({"note": e["note"]} if e.get("note") else {})}
+            return e["hbm_bytes_per_launch"], src
+    return None, {"reason": why}
 
 
 def build_pool(args):
@@ -138,7 +157,30 @@ def main():
     rdev = dev if backend == "nccl" else torch.device("cpu")  # where the cross-rank scalars live
 
     t_setup = time.time()
-    texts, zs = build_pool(args)
+    if world > 1:
+        # the pool is built ONCE, on rank 0 (8,192 level-6 compressions: ~11 s of one host core -- times N on the node's shared
+        # cores if every rank did it), and handed to the others: lengths, then the bytes
+        if rank == 0:
+            texts, zs = build_pool(args)
+            lens = torch.tensor([len(t) for t in texts] + [len(z) for z in zs], dtype=torch.int64)
+            blob = torch.from_numpy(np.frombuffer(b"".join(texts) + b"".join(zs), dtype=np.uint8).copy())
+        else:
+            lens = torch.zeros(2 * args.pool, dtype=torch.int64)
+        lens = lens.to(rdev)
+        dist.broadcast(lens, src=0)
+        lens_h = lens.cpu().numpy()
+        if rank != 0:
+            blob = torch.zeros(int(lens_h.sum()), dtype=torch.uint8)
+        blob = blob.to(rdev)
+        dist.broadcast(blob, src=0)
+        if rank != 0:
+            raw = blob.cpu().numpy().tobytes()
+            cuts = np.concatenate([[0], np.cumsum(lens_h)])
+            pieces = [raw[int(cuts[k]):int(cuts[k + 1])] for k in range(2 * args.pool)]
+            texts, zs = pieces[:args.pool], pieces[args.pool:]
+        del blob
+    else:
+        texts, zs = build_pool(args)
     npool = len(zs)
     total_streams = args.streams * world
     rng = np.random.default_rng(0xB00C)
@@ -204,12 +246,24 @@ def main():
         step()
         kernel_ms.append(ctx.last_kernel_ms())  # HIP events on the launch stream (waits for the step)
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # this rank's K steps, between a barrier + synchronize in front and a synchronize behind
     barrier()
-    elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # the job's time is the slowest rank's (MAX); every rank's own wall time, kernel time and share are reported beside it
+        mine_v = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(out_cap.sum()), float(in_len.sum()), float(n)], dtype=torch.float64, device=rdev)
+        allv = [torch.zeros_like(mine_v) for _ in range(world)]
+        dist.all_gather(allv, mine_v)
+        allv = np.stack([v.cpu().numpy() for v in allv])
+        elapsed = float(allv[:, 0].max())
+        per_rank = {"wall_ms_per_step": [round(float(x) / args.steps * 1e3, 3) for x in allv[:, 0]],
+                    "kernel_ms": [round(float(x), 3) for x in allv[:, 1]],
+                    "kernel_ms_min": round(float(allv[:, 1].min()), 3), "kernel_ms_max": round(float(allv[:, 1].max()), 3),
+                    "decoded_MiB": [round(float(x) / 2**20, 1) for x in allv[:, 2]],
+                    "streams": [int(x) for x in allv[:, 4]],
+                    "shard_imbalance": round(float(allv[:, 2].max() / allv[:, 2].mean()), 4),
+                    "note": "time = MAX over ranks of the rank's own wall time for its K steps (barrier + synchronize in front, synchronize behind, "
+                            "the closing barrier outside); shard_imbalance = largest shard's decoded bytes / mean"}
 
     # ---- verification: EVERY stream of the timed batch, bit-exact ---------------------------------
     # The outputs are POISONED first and one more step -- the same call on the same arenas, outside the timed region -- is
@@ -274,7 +328,9 @@ def main():
               "note": "whole DEFLATE window as an LDS ring: 4 stream-waves per CU (LDS-bound occupancy)"}
         ctx.set_ring_bits(ring_bits)
 
-    dec_total = int(out_cap.sum()) * world  # decoded bytes per step, whole job (every rank holds the same amount)
+    dec_total = int(out_cap.sum()) * world  # decoded bytes per step, whole job (the shards hold the same amount: plan_shards balances them)
+    if per_rank is not None:
+        dec_total = int(allv[:, 2].sum())
     comp_total = int(in_len.sum())
     value = dec_total * args.steps / elapsed / 2**30
 
@@ -316,9 +372,10 @@ def main():
                 "ring_bits": ring_bits,
                 **({"container": "gzip members (extension): CRC-32 + ISIZE verified by a second kernel"} if args.gzip else {}),
                 "window": "32 KiB LDS ring" if ring_bits == 15 else f"{2**ring_bits // 1024} KiB LDS near ring + far back-references from the stream's flushed output (HBM/L2)",
-                "decode": "strips: 64 lanes decode 64 consecutive pieces of a stream's input token by token (speculative starts, verified), "
-                          "tokens through a per-wave scratch in HBM (52.5 KiB per resident stream-wave, allocated by the library); 128-bit "
-                          "windows for stream tails and short streams",
+                "decode": "strips: 64 lanes decode 64 consecutive pieces of a stream's input token by token (speculative starts, verified) and write "
+                          "them as sequences (literal run + match: a record and the literal bytes) to a per-wave scratch in HBM (64.5 KiB per resident "
+                          "stream-wave, allocated by the library); then one lane copies one whole sequence inside the LDS ring, up to 64 sequences a "
+                          "group; 128-bit windows for stream tails and short streams",
                 "verified": ("every stream: status, length, in_used, Adler-32 and full byte compare, on one more step run after the "
                              "timed region over POISONED output / status arrays") if bit_exact is not None else "skipped",
             },
@@ -340,6 +397,8 @@ def main():
         }
         if ab is not None:
             result["lds_ring_32k_variant"] = ab
+        if per_rank is not None:
+            result["per_rank"] = per_rank
 
     # ---- BASELINE configs 3 and 5 and the 64 KiB batch of SURVEY.md 8d in the same run: one launch each over
     # arenas resident in HBM, three timed launches (HIP events), every stream verified (status, length, in_used, Adler-32, every
@@ -396,19 +455,33 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_path:
         h_out = np.empty(int(d_out.numel()), dtype=np.uint8)
         ctx.decompress_many_raw(h_in, in_off, in_len, h_out, out_off, out_cap)  # warm the staging buffers
-        dth = None
-        for _ in range(2):  # (the better of two calls, as the page-locked leg below: the copies by the host's helper threads vary with the box)
+
+        def every_stream_equal(arena):
+            """Every stream's bytes in a host output arena against the plaintext it was compressed from."""
+            if len(set(dec_len.tolist())) == 1:
+                width = int(dec_len[0])
+                stride = (width + 255) // 256 * 256
+                pool_np = np.frombuffer(b"".join(texts), dtype=np.uint8).reshape(npool, width)
+                got_np = arena[:n * stride].reshape(n, stride)[:, :width]
+                return all(np.array_equal(got_np[lo:lo + 4096], pool_np[pick[lo:lo + 4096]]) for lo in range(0, n, 4096))
+            return all(arena[int(out_off[k]):int(out_off[k]) + int(out_cap[k])].tobytes() == texts[pick[k]] for k in range(n))
+
+        h_out[:] = 0xCD  # poisoned, then a call whose results are verified: EVERY stream's status, length and bytes
+        o_len, o_st, _det, _used, _ad = ctx.decompress_many_raw(h_in, in_off, in_len, h_out, out_off, out_cap)
+        ok_h = bool((o_st == 0).all() and (o_len == out_cap).all()) and (args.no_verify or every_stream_equal(h_out))
+        dts = []
+        for _ in range(5):  # (median of five calls, every sample listed: VERDICT r4 item 5)
             t0h = time.perf_counter()
             o_len, o_st, _det, _used, _ad = ctx.decompress_many_raw(h_in, in_off, in_len, h_out, out_off, out_cap)
-            dt1 = time.perf_counter() - t0h
-            dth = dt1 if dth is None else min(dth, dt1)
-        k0 = int(n // 2)
-        ok_h = bool((o_st == 0).all() and (o_len == out_cap).all()
-                    and h_out[int(out_off[k0]):int(out_off[k0]) + int(out_cap[k0])].tobytes() == texts[pick[k0]])
+            dts.append(time.perf_counter() - t0h)
+            ok_h = ok_h and bool((o_st == 0).all() and (o_len == out_cap).all())
+        dth = float(np.median(dts))
         result["host_buffers_variant"] = {
             "GiBps": round(int(out_cap.sum()) / dth / 2**30, 2), "ms": round(dth * 1e3, 1), "ok": ok_h,
+            "ms_samples": [round(x * 1e3, 1) for x in dts],
+            "verified": "every stream: status, length and every byte, on a call over a poisoned arena",
             "note": "pageable host arenas in and out through pzg_decompress_many without PZG_DEVICE_PTRS: "
-                    "pinned staging + PCIe both ways + kernel, one call (the better of two)",
+                    "pinned staging + PCIe both ways + kernel, one call (median of five)",
         }
         del h_out
         # ... and as PAGE-LOCKED arenas (pzg_host_alloc + PZG_HOST_PINNED: what the module mirrors hand over): the copy engines
@@ -422,19 +495,20 @@ def main():
             o_len, o_st, _det, _used, o_ad = ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
             ok_p = bool((o_st == 0).all() and (o_len == out_cap).all() and (o_ad == exp_adler).all()) if not args.no_verify else None
             if ok_p:
-                for k0 in range(0, n, max(1, n // 64)):
-                    ok_p = ok_p and p_out.a[int(out_off[k0]):int(out_off[k0]) + int(out_cap[k0])].tobytes() == texts[pick[k0]]
-            dtp = None
-            for _ in range(2):  # ... then two timed ones over the arena as it stands (freshly CPU-written lines slow the copy engine's writes down)
+                ok_p = every_stream_equal(p_out.a)
+            dtps = []
+            for _ in range(5):  # ... then five timed ones over the arena as it stands (freshly CPU-written lines slow the copy engine's writes down)
                 t0h = time.perf_counter()
                 o_len, o_st, _det, _used, o_ad = ctx.decompress_many_raw(p_in.a, in_off, in_len, p_out.a, out_off, out_cap, pinned=True)
-                dt1 = time.perf_counter() - t0h
-                dtp = dt1 if dtp is None else min(dtp, dt1)
+                dtps.append(time.perf_counter() - t0h)
                 if ok_p is not None:
                     ok_p = ok_p and bool((o_st == 0).all() and (o_ad == exp_adler).all())
+            dtp = float(np.median(dtps))
             result["host_buffers_variant"]["pinned"] = {
                 "GiBps": round(int(out_cap.sum()) / dtp / 2**30, 2), "ms": round(dtp * 1e3, 1), "ok": ok_p,
-                "note": "the same batch in page-locked arenas (pzg_host_alloc) with PZG_HOST_PINNED: PCIe both ways + kernel, no staging copy",
+                "ms_samples": [round(x * 1e3, 1) for x in dtps],
+                "note": "the same batch in page-locked arenas (pzg_host_alloc) with PZG_HOST_PINNED: PCIe both ways + kernel, no staging copy "
+                        "(median of five; every stream's bytes verified on a call over a poisoned arena)",
             }
             p_in.close()
             p_out.close()

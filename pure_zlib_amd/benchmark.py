@@ -31,13 +31,13 @@ READ_CHUNK = 32768  # L.readFile hands out defaultChunkSize pieces (SURVEY.md 8a
 
 
 def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_decoders: int = 4096, piece: int = 32768,
-                           room: int = 192 * 1024) -> Dict[str, object]:
+                           room: int = 192 * 1024, passes: int = 5) -> Dict[str, object]:
     """Throughput of the incremental path (Benchmark.hs:53-70 benches `decompressIncremental` per fixture; this is its
     batched form): n_decoders resumable decoders, decoder k on streams[k % len(streams)], every one fed `piece` input
     bytes per pzg_decoder_feed call -- one launch per call, host buffers both ways.  Only the feed calls are timed (the
     host-side bookkeeping a caller does between feeds -- unconsumed tails in front of the next pieces -- is not).  Every
-    decoder's output is compared with plain[k % len(plain)].  Three passes over fresh decoders: the first sizes the
-    library's page-locked staging, the better of the other two is the one reported."""
+    decoder's output is compared with plain[k % len(plain)].  One pass over fresh decoders sizes the library's page-locked
+    staging; `passes` more are measured and their MEDIAN is reported, every sample listed."""
     import ctypes as C
     import numpy as np
     from . import _ffi
@@ -104,14 +104,16 @@ def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_deco
                 "us_per_decoder_feed": round(t_calls / n_feeds * 1e6, 2), "ok": bool(ok)}
 
     try:
-        first = one_pass()
-        res = one_pass()
-        again = one_pass()  # (the better of two measured passes: the host's share of a feed -- packing, copy-out -- varies with the box)
-        ok = bool(res["ok"] and first["ok"] and again["ok"])
-        if again["GiBps"] > res["GiBps"]:
-            res = again
-        res["ok"] = ok
+        first = one_pass()  # (its feed calls also allocate and page-lock the library's staging for this many decoders: not a measurement)
+        runs = [one_pass() for _ in range(passes)]
+        runs_sorted = sorted(runs, key=lambda r: r["GiBps"])
+        res = dict(runs_sorted[len(runs_sorted) // 2])  # the MEDIAN pass (no best-of)
+        res["ok"] = bool(first["ok"] and all(r["ok"] for r in runs))
+        res["GiBps_samples"] = [r["GiBps"] for r in runs]
+        res["measured"] = f"median of {passes} passes over fresh decoders (all samples listed), after one pass that sizes the staging"
         res["first_pass_GiBps"] = first["GiBps"]
+        res["first_pass_note"] = ("the first pass' feed calls allocate and page-lock the library's staging buffers and device arenas for this "
+                                  "many decoders (grow-only, kept by the context): a one-time cost, not a rate")
         return res
     finally:
         L.pzg_decoder_destroy(h)
