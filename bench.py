@@ -50,7 +50,7 @@ def kernel_sha256():
 
 def traffic_from_profiles(args, ring_bits, n):
     """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, counters only) of
-    this same command, recorded in profiles/traffic.json after each profiling session (tests/tools/traffic_passes.sh) together
+    this same command, recorded in profiles/traffic.json after each profiling session (tests/tools/r5_profiles.sh, tests/tools/traffic_update.py) together
     with the SHA-256 of the kernels' source and the pool size of the run.  Returns (bytes or None, where the number comes
     from -- or WHY there is none: an entry measured on other kernel source, or with another pool, is not this kernel's traffic)."""
     try:
@@ -63,7 +63,7 @@ def traffic_from_profiles(args, ring_bits, n):
     for e in t["entries"]:
         if e["workload"] == args.workload and e["ring_bits"] == ring_bits and e["streams"] == n and bool(e.get("gzip")) == bool(args.gzip):
             if e.get("kernel_sha256") != sha:
-                why = f"the entry was measured on other kernel source (sha256 {str(e.get('kernel_sha256'))[:12]}..., this build {sha[:12]}...): re-run tests/tools/traffic_passes.sh"
+                why = f"the entry was measured on other kernel source (sha256 {str(e.get('kernel_sha256'))[:12]}..., this build {sha[:12]}...): re-run tests/tools/r5_profiles.sh traffic + tests/tools/traffic_update.py"
                 continue
             if e.get("pool") not in (None, args.pool):
                 why = f"the entry was measured with --pool {e.get('pool')}, this run uses {args.pool}"

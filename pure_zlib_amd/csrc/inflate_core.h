@@ -253,6 +253,8 @@ struct alignas(16) WaveLds {
     uint32_t fixed_ready;                // 0x51DF1BED while lit/dist tables hold the fixed code: survives from one stream to the
                                          // next on a persistent wave, so a batch of fixed-Huffman streams builds it once per wave
     uint8_t dump[64 + 12];               // where masked-off lanes store (see sel_store): keeps hot loops free of lane-dependent branches
+    uint32_t strip_back;                 // the strips' run-up in bits, as the wave's last spans taught it (strip_span): survives from one
+                                         // stream to the next on a persistent wave, like fixed_ready; anything out of range means "the default"
 };
 
 // ---- result of one stream -------------------------------------------------------------------
@@ -2081,7 +2083,19 @@ struct Decoder {
     static constexpr uint32_t REG_RECA = (REG_LITA + STRIP_TMAX + 4u * SEQ_G + 31u) & ~31u;
     static constexpr uint32_t REG_BYTES = (REG_RECA + 4u * STRIP_TMAX + 63u) & ~63u;
     static constexpr uint32_t STRIP_WORDS = 64u * (REG_BYTES / 4u) + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
-    static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits
+    static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits: where a wave starts, and the most it uses
+    // Round 5: the run-up ADAPTS.  How fast a wrong start falls back onto the real chain of tokens depends on the code: measured
+    // with a fixed run-up of 256 / 384 / 512 / 768 bits, text 257 / 261 / 268 / 276 GiB/s and config 3 119 / 136 / 144 / 148 (a lane
+    // that starts wrong costs a whole round of phase B) -- but literal-heavy data 139 / 136 / 133 / 128: its short literal codes
+    // re-synchronise within a few dozen bits and the long run-up is wasted work.  So a span that needed no repair shortens the
+    // wave's run-up by STRIP_BACK_DOWN bits, one that did lengthens it by STRIP_BACK_UP: it settles where about one span in
+    // (1 + UP / DOWN) needs a repair.  The value lives in the wave's LDS across streams (a batch is mostly one kind of data).
+    // Nothing about the result depends on it.
+#ifndef PZG_STRIP_BACK_MIN
+#define PZG_STRIP_BACK_MIN 256
+#endif
+    static constexpr uint32_t STRIP_BACK_MIN = PZG_STRIP_BACK_MIN < PZG_STRIP_BACK ? PZG_STRIP_BACK_MIN : PZG_STRIP_BACK;
+    static constexpr uint32_t STRIP_BACK_DOWN = 32u, STRIP_BACK_UP = 256u;
 #ifndef PZG_STRIP_CMIN
 #define PZG_STRIP_CMIN 256
 #endif
@@ -2440,12 +2454,14 @@ struct Decoder {
         const bool lsub = !FX && lit_sub_used != 0u, dsub = !FX && dist_sub_used != 0u;
         PZG_T0(tsa);
         // phase A: the run-up
+        uint32_t back = uni(L.strip_back);
+        if (back < STRIP_BACK_MIN || back > STRIP_BACK) back = STRIP_BACK;
         StripReader rd;
         LaneVec<uint32_t> P, S, LIM;
         PZG_LANES_BEGIN(k)
             const uint32_t lo = k * C;
             PZG_LV(LIM, k) = r0 + lo;
-            const uint32_t p = r0 + (lo > STRIP_BACK ? lo - STRIP_BACK : 0u);  // (from the cursor itself: exact)
+            const uint32_t p = r0 + (lo > back ? lo - back : 0u);  // (from the cursor itself: exact)
             PZG_LV(P, k) = p;
             strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
             PZG_SR(TA) = PZG_SR(TB) = 0ull;
@@ -2472,8 +2488,10 @@ struct Decoder {
         PZG_LANES_END
         uint64_t dirty = ~0ull, stopm = 0ull;
         uint32_t last = 63u;
+        bool repaired = false;
         for (uint32_t round = 0;;) {
             if (round != 0u) {  // the lanes that start again, from where their neighbour's chain arrived
+                repaired = true;
                 PZG_LANES_BEGIN(k)
                     if (lane_bit(dirty, k)) {
                         const uint32_t p = PZG_LV(S, k);
@@ -2511,6 +2529,11 @@ struct Decoder {
             PZG_LANES_BEGIN(k)
                 PZG_LV(S, k) = PZG_LV(BAD, k) ? PZG_LV(NS, k) : PZG_LV(S, k);
             PZG_LANES_END
+        }
+        {   // what the next span's run-up learns from this one: the first round's guesses all held, or not
+            const uint32_t nb = !(repaired || dirty != 0ull) ? (back >= STRIP_BACK_MIN + STRIP_BACK_DOWN ? back - STRIP_BACK_DOWN : STRIP_BACK_MIN)
+                                            : (back + STRIP_BACK_UP <= STRIP_BACK ? back + STRIP_BACK_UP : STRIP_BACK);
+            if (lane_id() == 0u || PZG_WAVE == 1u) L.strip_back = nb;
         }
         if (dirty != 0ull) {  // still a lane that started in the wrong place: the span ends in front of it
             last = ctz64(dirty) - 1u;

@@ -157,6 +157,11 @@ def test_bench_py_two_ranks_on_one_device():
     # whole-job value: both ranks' bytes over the max-over-ranks time
     assert abs(r["value"] - 2 * 4096 * 32768 / (r["ms_per_step"] * 1e-3) / 2**30) / r["value"] < 0.02
     assert "cpu_baseline" not in r and r["roofline"]["frac"] > 0
+    # every rank's own time and share beside the job's (the job's time is the slowest rank's)
+    pr = r["per_rank"]
+    assert len(pr["kernel_ms"]) == 2 and len(pr["wall_ms_per_step"]) == 2 and pr["streams"] == [4096, 4096]
+    assert pr["kernel_ms_min"] <= pr["kernel_ms_max"] and abs(max(pr["wall_ms_per_step"]) - r["ms_per_step"]) < 1e-3
+    assert 1.0 <= pr["shard_imbalance"] < 1.01
 
 
 def test_bench_py_config5_command_two_ranks():
@@ -166,6 +171,7 @@ def test_bench_py_config5_command_two_ranks():
     r = _bench_two_ranks(["--workload", "mixed", "--streams", "16384"])
     assert 14000 < r["config"]["streams_per_gpu"] < 19000 and r["config"]["parallelism"] == "shard2"  # (balanced by bytes, not by count)
     assert "config 5" in r["config"]["workload"] and r["value"] > 0
+    assert sum(r["per_rank"]["streams"]) == 2 * 16384 and 1.0 <= r["per_rank"]["shard_imbalance"] < 1.05
 
 
 def test_adler32_over_one_16_gib_device_buffer(gpu_ctx):
