@@ -2840,16 +2840,17 @@ struct Decoder {
             PZG_LV(ENDX, j) = (nl + len) | (nl << 16);
         PZG_LANES_END
         lanes_iscan_add(ENDX);  // (64 x 513 and 64 x 255: both halves stay below 2^16)
-        LaneVec<bool> OVER, BAD, MIX;
+        LaneVec<bool> OVER, BAD, MIX, HASM;
         PZG_LANES_BEGIN(j)
             const uint32_t end = PZG_LV(ENDX, j) & 0xffffu, len = PZG_LV(LEN, j), m = end - len;
             PZG_LV(MO, j) = m;  // the match's first byte, relative to op (its literals end there)
             PZG_LV(OVER, j) = end > SEQ_GLIM;
-            PZG_LV(BAD, j) = (len != 0u) & (PZG_LV(DIST, j) > hist + m);  // reaches in front of the output: seq_solo() reports it
+            PZG_LV(HASM, j) = len != 0u;
+            PZG_LV(BAD, j) = PZG_LV(DIST, j) > hist + m;  // (of a match:) reaches in front of the output: seq_solo() reports it
             // the 32 KiB ring keeps nothing else: a source the group's own bytes would overwrite first
-            PZG_LV(MIX, j) = RING_BITS == 15 && (len != 0u) & ((int32_t)(m - PZG_LV(DIST, j)) < (int32_t)(SEQ_GLIM - RING));
+            PZG_LV(MIX, j) = (int32_t)(m - PZG_LV(DIST, j)) < (int32_t)(SEQ_GLIM - RING);
         PZG_LANES_END
-        const uint64_t stopm = lanes_ballot(OVER) | lanes_ballot(BAD) | (RING_BITS == 15 ? lanes_ballot(MIX) : 0ull);
+        const uint64_t stopm = lanes_ballot(OVER) | (lanes_ballot(HASM) & (lanes_ballot(BAD) | (RING_BITS == 15 ? lanes_ballot(MIX) : 0ull)));
         const uint32_t v0 = stopm ? ctz64(stopm) : n;
         const uint32_t v = v0 < n ? v0 : n;  // sequences of this group
         if (__builtin_expect(v == 0u, 0)) return SQ_SOLO;
@@ -2858,57 +2859,62 @@ struct Decoder {
         PZG_STAT(20, 1);    // groups
         PZG_STAT(21, v);    // their sequences
         PZG_STAT(22, run);  // their bytes
-        // ---- the matches: where they read and write
+        // ---- the matches: where they read and write.  (Every predicate is ONE compare, balloted at once, and the classes are put
+        // together on the masks by scalar instructions: a ballot of a compound predicate costs two vector instructions more.)
         SeqCopy c;
-        LaneVec<bool> NEAR, FARL, FARW, SLOW, N4, N3, COOP;
         LaneVec<uint32_t> SEND;
+        LaneVec<bool> B_LEN, B_NEAR, B_WD, B_WS, B_D16, B_OV, B_D4, B_BIG, B_L4, B_L3;
         PZG_LANES_BEGIN(j)
             const uint32_t len = PZG_LV(LEN, j), dist = PZG_LV(DIST, j), m = PZG_LV(MO, j);
-            const bool hasm = lane_bit(taken, j) & (len != 0u);
             const int32_t srcr = (int32_t)(m - dist);  // relative to op
-            const bool near = HYBRID ? hasm & (srcr >= (int32_t)(run - RING)) : hasm;  // still in the ring when the group's last byte is
             const uint32_t dm = (op32 + m) & RMASK, sm = (dm - dist) & RMASK;
-            const bool wrap_d = dm + len > RING, wrap_s = sm + len > RING;
-            const bool slow = wrap_d | wrap_s | ((dist < 16u) & ((len > dist) | (dist < 4u)));
-            const bool big = len > SEQ_CAP;  // all lanes together, when its turn comes (seq_coop)
             PZG_LV(c.LEN, j) = len;
             PZG_LV(c.DM, j) = dm;
             PZG_LV(c.SM, j) = sm;
             PZG_LV(c.NB, j) = (len - 1u) >> 2;
             PZG_LV(c.ST, j) = sm + len - 4u;
             PZG_LV(c.DT, j) = dm + len - 4u;
-            PZG_LV(NEAR, j) = near | (hasm & big);
-            PZG_LV(COOP, j) = hasm & big;
-            PZG_LV(SLOW, j) = near & slow & !big;
-            PZG_LV(N4, j) = near & !slow & !big & (len >= 4u);
-            PZG_LV(N3, j) = near & !slow & (len == 3u);
-            PZG_LV(FARL, j) = HYBRID && (hasm & !near & !big);
-            PZG_LV(FARW, j) = wrap_d;
+            PZG_LV(B_LEN, j) = len != 0u;
+            PZG_LV(B_NEAR, j) = srcr >= (int32_t)(run - RING);  // still in the ring when the group's last byte is
+            PZG_LV(B_WD, j) = dm + len > RING;
+            PZG_LV(B_WS, j) = sm + len > RING;
+            PZG_LV(B_D16, j) = dist < 16u;
+            PZG_LV(B_OV, j) = len > dist;
+            PZG_LV(B_D4, j) = dist < 4u;
+            PZG_LV(B_BIG, j) = len > SEQ_CAP;  // all lanes together, when its turn comes (seq_coop)
+            PZG_LV(B_L4, j) = len >= 4u;
+            PZG_LV(B_L3, j) = len == 3u;
             PZG_LV(SEND, j) = (uint32_t)srcr + (len < dist ? len : dist);  // where its source ends (signed, relative to op)
         PZG_LANES_END
-        c.norm4 = lanes_ballot(N4);
-        c.norm3 = lanes_ballot(N3);
-        c.slow = lanes_ballot(SLOW);
-        const uint64_t coopm = lanes_ballot(COOP);
-        const uint64_t nearm = lanes_ballot(NEAR), farm = HYBRID ? lanes_ballot(FARL) & far_okmask : 0ull;
+        const uint64_t hasm = taken & lanes_ballot(B_LEN), coopm = hasm & lanes_ballot(B_BIG);
+        const uint64_t nearx = HYBRID ? hasm & lanes_ballot(B_NEAR) & ~coopm : hasm & ~coopm;
+        const uint64_t wrapd = lanes_ballot(B_WD);
+        const uint64_t slowx = wrapd | lanes_ballot(B_WS) | (lanes_ballot(B_D16) & (lanes_ballot(B_OV) | lanes_ballot(B_D4)));
+        c.slow = nearx & slowx;
+        c.norm4 = nearx & ~slowx & lanes_ballot(B_L4);
+        c.norm3 = nearx & ~slowx & lanes_ballot(B_L3);
+        const uint64_t nearm = nearx | coopm;
+#if defined(PZG_LAB) && defined(PZG_LAB_NOFAR)  // (lab builds only: traffic attribution -- the far matches are not copied, the output is wrong)
+        const uint64_t farm = 0ull;
+#else
+        const uint64_t farm = HYBRID ? hasm & ~nearx & ~coopm & far_okmask : 0ull;
+#endif
         // ---- the far matches' sources: asked for.  They end SEQ_GLIM + ... bytes below `flushed` at the least (static_assert
         // above), in lines that are complete and final (see set_far_base).
         LaneVec<uint32_t> FO, FND, FX[4];
-        LaneVec<bool> FA[4];
+        const uint64_t farn = farm & ~wrapd, fars = farm & wrapd;
         if (HYBRID && farm != 0ull) {
             PZG_STAT(25, 1);
             far_fence();
             const uint32_t fdelta = (uint32_t)(op - flushed);
             PZG_LANES_BEGIN(j)
                 const uint32_t len = PZG_LV(c.LEN, j), l4 = len >= 4u ? len - 4u : 0u;
-                const bool fn = lane_bit(farm, j) & !PZG_LV(FARW, j);
-                const uint32_t nd = fn ? (len + 3u) >> 2 : 0u, fo = 32768u + fdelta + PZG_LV(MO, j) - PZG_LV(DIST, j);  // the source's first byte, from far_base
+                const uint32_t nd = mask_keep(farn, j, (len + 3u) >> 2), fo = 32768u + fdelta + PZG_LV(MO, j) - PZG_LV(DIST, j);  // the source's first byte, from far_base
                 PZG_LV(FND, j) = nd;
                 PZG_LV(FO, j) = fo;
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     const uint32_t off = 4u * u < l4 ? 4u * u : l4;
-                    PZG_LV(FA[u], j) = u < nd;
 #if PZG_DEVICE_PASS
                     PZG_LV(FX[u], j) = far_load32(u < nd ? fo + off : FAR_IDLE);
 #else
@@ -2937,20 +2943,24 @@ struct Decoder {
         PZG_MARK("g.lits");
         // ---- this group's literals: asked for
         LaneVec<uint32_t> LAD, DL, X0, X1;
-        LaneVec<bool> FASTL, SLOWL, MORE;
+        LaneVec<bool> B_NL, B_WL, B_N8, B_N5;
         PZG_LANES_BEGIN(j)
             const uint32_t nl = PZG_LV(NL, j);
-            const bool tk = lane_bit(taken, j) & (nl != 0u);
             const uint32_t la = reg_lit(PZG_LV(INFO, j) & 255u) + PZG_LV(CL, j) - nl, dl = (op32 + PZG_LV(MO, j) - nl) & RMASK;
-            const bool wrap = dl + nl > RING;
             PZG_LV(LAD, j) = la;
             PZG_LV(DL, j) = dl;
-            PZG_LV(FASTL, j) = tk & !wrap;
-            PZG_LV(SLOWL, j) = tk & wrap;
-            PZG_LV(MORE, j) = tk & !wrap & (nl > 8u);
+            PZG_LV(B_NL, j) = nl != 0u;
+            PZG_LV(B_WL, j) = dl + nl > RING;
+            PZG_LV(B_N8, j) = nl > 8u;
+            PZG_LV(B_N5, j) = nl > 4u;
+        PZG_LANES_END
+        const uint64_t litm = taken & lanes_ballot(B_NL), wrapl = lanes_ballot(B_WL), fastl = litm & ~wrapl, slowl = litm & wrapl;
+        const uint64_t morel = fastl & lanes_ballot(B_N8), fast5 = fastl & lanes_ballot(B_N5);
+        PZG_LANES_BEGIN(j)
+            const uint32_t nl = PZG_LV(NL, j), la = PZG_LV(LAD, j);
             const uint32_t off1 = nl - 4u < 4u ? nl - 4u : 4u;
-            PZG_LV(X0, j) = lit_load32((tk & !wrap) ? la : lit_a);
-            PZG_LV(X1, j) = lit_load32((tk & !wrap & (nl > 4u)) ? la + off1 : lit_a);
+            PZG_LV(X0, j) = lit_load32(mask_select(fastl, j, la, lit_a));
+            PZG_LV(X1, j) = lit_load32(mask_select(fast5, j, la + off1, lit_a));
         PZG_LANES_END
         PZG_SEQ_ACC(13, tq);
         PZG_MARK("g.matches");
@@ -2969,51 +2979,51 @@ struct Decoder {
         PZG_SEQ_ACC(14, tq);
         // ---- 1. the literal runs: byte t of the first dword where the run has more than t bytes, the second dword ends with the run
         {
-            LaneVec<bool> G2, G3, G4, G5;
+            LaneVec<bool> G2, G3, G4;
             LaneVec<uint32_t> DL1;
             PZG_LANES_BEGIN(j)
                 const uint32_t nl = PZG_LV(NL, j);
-                const bool f = PZG_LV(FASTL, j);
-                PZG_LV(G2, j) = f & (nl >= 2u);
-                PZG_LV(G3, j) = f & (nl >= 3u);
-                PZG_LV(G4, j) = f & (nl >= 4u);
-                PZG_LV(G5, j) = f & (nl > 4u);
+                PZG_LV(G2, j) = nl >= 2u;
+                PZG_LV(G3, j) = nl >= 3u;
+                PZG_LV(G4, j) = nl >= 4u;
                 PZG_LV(DL1, j) = PZG_LV(DL, j) + (nl - 4u < 4u ? nl - 4u : 4u);
             PZG_LANES_END
-            lds_put_bytes(DL, X0, lanes_ballot(FASTL), lanes_ballot(G2), lanes_ballot(G3), lanes_ballot(G4));
-            lds_put_dword(DL1, X1, lanes_ballot(G5));
+            lds_put_bytes(DL, X0, fastl, fastl & lanes_ballot(G2), fastl & lanes_ballot(G3), fastl & lanes_ballot(G4));
+            lds_put_dword(DL1, X1, fast5);
         }
-        if (__builtin_expect(lanes_ballot(MORE) != 0ull, 0)) {  // runs of more than 8 literals: two dwords a step
+        if (__builtin_expect(morel != 0ull, 0)) {  // runs of more than 8 literals: two dwords a step
             LaneVec<bool> A0, A1;
             for (uint32_t i = 2u;; i += 2u) {
                 PZG_LANES_BEGIN(j)
                     const uint32_t nd = (PZG_LV(NL, j) + 3u) >> 2;
-                    PZG_LV(A0, j) = PZG_LV(MORE, j) & (i < nd);
-                    PZG_LV(A1, j) = PZG_LV(MORE, j) & (i + 1u < nd);
+                    PZG_LV(A0, j) = i < nd;
+                    PZG_LV(A1, j) = i + 1u < nd;
                 PZG_LANES_END
-                if (lanes_ballot(A0) == 0ull) break;
+                const uint64_t a0 = morel & lanes_ballot(A0), a1 = morel & lanes_ballot(A1);
+                if (a0 == 0ull) break;
                 LaneVec<uint32_t> Y0, Y1, D0, D1;
                 PZG_LANES_BEGIN(j)
                     const uint32_t l4 = PZG_LV(NL, j) - 4u, o0 = 4u * i < l4 ? 4u * i : l4, o1 = 4u * i + 4u < l4 ? 4u * i + 4u : l4;
-                    PZG_LV(Y0, j) = lit_load32(PZG_LV(A0, j) ? PZG_LV(LAD, j) + o0 : lit_a);
-                    PZG_LV(Y1, j) = lit_load32(PZG_LV(A1, j) ? PZG_LV(LAD, j) + o1 : lit_a);
+                    PZG_LV(Y0, j) = lit_load32(mask_select(a0, j, PZG_LV(LAD, j) + o0, lit_a));
+                    PZG_LV(Y1, j) = lit_load32(mask_select(a1, j, PZG_LV(LAD, j) + o1, lit_a));
                     PZG_LV(D0, j) = PZG_LV(DL, j) + o0;
                     PZG_LV(D1, j) = PZG_LV(DL, j) + o1;
                 PZG_LANES_END
-                lds_put_dword(D0, Y0, lanes_ballot(A0));
-                lds_put_dword(D1, Y1, lanes_ballot(A1));
+                lds_put_dword(D0, Y0, a0);
+                lds_put_dword(D1, Y1, a1);
             }
         }
-        if (__builtin_expect(lanes_ballot(SLOWL) != 0ull, 0)) {  // the run that wraps around the ring's end: byte by byte
+        if (__builtin_expect(slowl != 0ull, 0)) {  // the run that wraps around the ring's end: byte by byte
             LaneVec<bool> A0;
             for (uint32_t i = 0;; ++i) {
                 PZG_LANES_BEGIN(j)
-                    PZG_LV(A0, j) = PZG_LV(SLOWL, j) & (i < PZG_LV(NL, j));
+                    PZG_LV(A0, j) = i < PZG_LV(NL, j);
                 PZG_LANES_END
-                if (lanes_ballot(A0) == 0ull) break;
+                const uint64_t a0 = slowl & lanes_ballot(A0);
+                if (a0 == 0ull) break;
                 PZG_LANES_BEGIN(j)
-                    const uint8_t b = lit_load8(PZG_LV(A0, j) ? PZG_LV(LAD, j) + i : lit_a);
-                    ring_store(PZG_LV(A0, j), (PZG_LV(DL, j) + i) & RMASK, b, j);
+                    const uint8_t b = lit_load8(mask_select(a0, j, PZG_LV(LAD, j) + i, lit_a));
+                    ring_store(lane_bit(a0, j), (PZG_LV(DL, j) + i) & RMASK, b, j);
                 PZG_LANES_END
             }
         }
@@ -3021,22 +3031,26 @@ struct Decoder {
         PZG_MARK("g.far");
         // ---- 2b. the far matches
         if (HYBRID && farm != 0ull) {
+            LaneVec<bool> FL4, FL3;
+            PZG_LANES_BEGIN(j)
+                PZG_LV(FL4, j) = PZG_LV(c.LEN, j) >= 4u;
+                PZG_LV(FL3, j) = PZG_LV(c.LEN, j) == 3u;
+            PZG_LANES_END
+            const uint64_t far4 = farn & lanes_ballot(FL4), far3 = farn & lanes_ballot(FL3);
             for (uint32_t i0 = 0;;) {
                 LaneVec<uint32_t> FD[4];
-                LaneVec<bool> F3;
+                LaneVec<bool> FA[4];
                 PZG_LANES_BEGIN(j)
                     const uint32_t len = PZG_LV(c.LEN, j), l4 = len >= 4u ? len - 4u : 0u, dm = PZG_LV(c.DM, j);
 #pragma unroll
                     for (uint32_t u = 0; u < 4u; ++u) {
                         PZG_LV(FD[u], j) = dm + (4u * (i0 + u) < l4 ? 4u * (i0 + u) : l4);
-                        PZG_LV(FA[u], j) = PZG_LV(FA[u], j) & (len >= 4u);
+                        PZG_LV(FA[u], j) = i0 + u < PZG_LV(FND, j);
                     }
-                    PZG_LV(F3, j) = (i0 == 0u) & (PZG_LV(FND, j) != 0u) & (len == 3u);  // (a three-byte match is one load)
                 PZG_LANES_END
-                const uint64_t f3 = lanes_ballot(F3);
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) lds_put_dword(FD[u], FX[u], lanes_ballot(FA[u]));
-                lds_put_bytes(c.DM, FX[0], f3, f3, f3, 0ull);
+                for (uint32_t u = 0; u < 4u; ++u) lds_put_dword(FD[u], FX[u], far4 & lanes_ballot(FA[u]));
+                if (i0 == 0u) lds_put_bytes(c.DM, FX[0], far3, far3, far3, 0ull);  // (a three-byte match is one load)
                 i0 += 4u;
                 PZG_LANES_BEGIN(j)
 #pragma unroll
@@ -3056,23 +3070,21 @@ struct Decoder {
                     }
                 PZG_LANES_END
             }
-            LaneVec<bool> FS;
-            PZG_LANES_BEGIN(j)
-                PZG_LV(FS, j) = lane_bit(farm, j) & PZG_LV(FARW, j);
-            PZG_LANES_END
-            if (__builtin_expect(lanes_ballot(FS) != 0ull, 0)) {  // a far match whose output wraps around the ring's end
+            if (__builtin_expect(fars != 0ull, 0)) {  // a far match whose output wraps around the ring's end
+                LaneVec<bool> A0;
                 for (uint32_t i = 0;; ++i) {
                     PZG_LANES_BEGIN(j)
-                        PZG_LV(FA[0], j) = PZG_LV(FS, j) & (i < PZG_LV(c.LEN, j));
+                        PZG_LV(A0, j) = i < PZG_LV(c.LEN, j);
                     PZG_LANES_END
-                    if (lanes_ballot(FA[0]) == 0ull) break;
+                    const uint64_t a0 = fars & lanes_ballot(A0);
+                    if (a0 == 0ull) break;
                     PZG_LANES_BEGIN(j)
 #if PZG_DEVICE_PASS
-                        const uint8_t b = far_base[PZG_LV(FA[0], j) ? PZG_LV(FO, j) + i : FAR_IDLE];
+                        const uint8_t b = far_base[mask_select(a0, j, PZG_LV(FO, j) + i, FAR_IDLE)];
 #else
-                        const uint8_t b = PZG_LV(FA[0], j) ? far_base[PZG_LV(FO, j) + i] : (uint8_t)0;
+                        const uint8_t b = lane_bit(a0, j) ? far_base[PZG_LV(FO, j) + i] : (uint8_t)0;
 #endif
-                        ring_store(PZG_LV(FA[0], j), (PZG_LV(c.DM, j) + i) & RMASK, b, j);
+                        ring_store(lane_bit(a0, j), (PZG_LV(c.DM, j) + i) & RMASK, b, j);
                     PZG_LANES_END
                 }
             }
