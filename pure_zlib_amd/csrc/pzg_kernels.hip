@@ -25,9 +25,12 @@ namespace pzg {
 #endif
 // (the gzip instance of ring 11 needs more vector registers than the zlib one: five waves per SIMD, 20 stream-waves per CU
 // instead of 26 -- with the strips the kernels' speed levels off at ~20 per CU anyway -- and nothing in scratch)
+#ifndef PZG_MIN_WAVES_11_GZIP
+#define PZG_MIN_WAVES_11_GZIP 5
+#endif
 constexpr int waves_per_simd(int ring_bits, bool gzip = false)
 {
-    return ring_bits <= 11 ? (gzip ? 5 : PZG_MIN_WAVES_11) : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
+    return ring_bits <= 11 ? (gzip ? PZG_MIN_WAVES_11_GZIP : PZG_MIN_WAVES_11) : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
 }
 template <int RING_BITS, bool GZIP = false>
 constexpr uint32_t waves_per_cu()
