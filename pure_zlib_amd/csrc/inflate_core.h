@@ -2964,6 +2964,22 @@ struct Decoder {
         PZG_LANES_END
         PZG_SEQ_ACC(13, tq);
         PZG_MARK("g.matches");
+#if defined(PZG_STATS) && !PZG_DEVICE_PASS
+        {   // (lab statistics: the true depth of the group's dependencies -- rounds an exact rule would need)
+            uint32_t lvl[64], maxl = 0;
+            for (uint32_t j = 0; j < 64u; ++j) {
+                lvl[j] = 0;
+                if (!((hasm >> j) & 1ull)) continue;
+                const int32_t sj = (int32_t)(PZG_LV(MO, j) - PZG_LV(DIST, j)), ej = (int32_t)PZG_LV(SEND, j);
+                uint32_t l = 1;
+                for (uint32_t i = 0; i < j; ++i)
+                    if (((hasm >> i) & 1ull) && (int32_t)PZG_LV(MO, i) < ej && (int32_t)(PZG_LV(MO, i) + PZG_LV(LEN, i)) > sj && lvl[i] + 1u > l) l = lvl[i] + 1u;
+                lvl[j] = l;
+                if (l > maxl) maxl = l;
+            }
+            PZG_STAT(28, maxl);
+        }
+#endif
         // ---- 2a. the matches that read nothing of this group (most of them), while the loads are on their way
         uint64_t pend = nearm;
         if (nearm != 0ull) {

@@ -15,7 +15,7 @@ NAMES = ["windows (hot loop)", "tokens queued by clean windows", "segments", "se
          "ended by a source inside the segment", "ended by the queue running out", "sum of qn at segment start", "bytes of segments",
          "tokens of segments", "segments with a second pass", "head token for copy_match / bail", "checked steps",
          "strip spans", "records of strip spans", "phase-B rounds", "phase-A steps", "phase-B steps", "spans cut at a wrong start", "lanes that counted",
-         "groups", "sequences of groups", "bytes of groups", "copy rounds", "solo sequences + long matches in groups", "groups with far matches", "dword steps", "byte steps"]
+         "groups", "sequences of groups", "bytes of groups", "copy rounds", "solo sequences + long matches in groups", "groups with far matches", "dword steps", "byte steps", "sum of exact dependency depths"]
 
 
 def build():
@@ -68,7 +68,7 @@ def main():
           f"tokens per segment {v[9] / max(v[2] - v[11], 1):.1f}; qn at segment start {v[7] / max(v[2], 1):.1f}")
     g = max(v[20], 1)
     print(f"  per group: sequences {v[21] / g:.1f}; bytes {v[22] / g:.1f}; copy rounds {v[23] / g:.2f}; dword steps {v[26] / g:.1f}; byte steps {v[27] / g:.2f}; "
-          f"with far matches {v[25] / g:.2f}; solo per group {v[24] / g:.3f}")
+          f"with far matches {v[25] / g:.2f}; solo per group {v[24] / g:.3f}; exact dependency depth {v[28] / g:.2f}")
 
 
 if __name__ == "__main__":
