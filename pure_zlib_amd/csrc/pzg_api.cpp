@@ -48,6 +48,10 @@ struct CallThread {
     template <class F>
     bool start(F &&body)
     {
+#if defined(PZG_LAB) && defined(PZG_LAB_NO_CALL_THREADS)  // (lab builds only, tests/test_gpu_api.py: as if the system had no thread to give)
+        (void)body;
+        return false;
+#endif
         try {
             t = std::thread(std::forward<F>(body));
             return true;

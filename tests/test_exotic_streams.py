@@ -108,6 +108,16 @@ def test_model_exotic_streams_when_the_guesses_fail(model_poor, oracle):
             assert same(ro2, oo2, rm, om), (seed, c, note, ro2.status, rm.status)
 
 
+NOTHREADS_FLAGS = ["-DPZG_LAB", "-DPZG_LAB_NO_CALL_THREADS"]  # the host paths' helper threads of a call cannot be started: the stages run inline
+
+
+def test_lab_library_without_call_threads_builds():
+    """build/lab_nothreads/libpzg.so (for tests/test_gpu_api.py::test_host_paths_when_no_thread_can_be_started) builds here and
+    travels to the GPU box with the snapshot."""
+    so = lab_library("nothreads", NOTHREADS_FLAGS)
+    assert b"hipv4-amdgcn-amd-amdhsa--gfx950" in open(so, "rb").read()
+
+
 def test_lab_library_with_failing_guesses_builds():
     """build/lab_poor/libpzg.so (the device build of the same experiment, for tests/test_gpu_parity.py) builds here, carries a
     gfx950 code object, and travels to the GPU box with the snapshot."""

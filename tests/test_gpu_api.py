@@ -271,6 +271,63 @@ print("noflags parity ok", len(streams))
     assert out.returncode == 0 and "noflags parity ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
 
 
+def test_host_paths_when_no_thread_can_be_started(tmp_path):
+    """the pipelined host paths start helper threads per call (a drainer in the staged / page-locked batch path,
+    a drainer and a copier in a large pzg_decoder_feed).  They are joined whatever way the call ends, and when the system has no
+    thread to give the issuing thread runs their stages itself.  build/lab_nothreads/libpzg.so is the product with thread creation
+    made to fail (tests/tools/lab_build.sh): a staged batch of several ranges, the same batch in page-locked arenas, and a feed of
+    600 decoders x 128 KiB (the pipelined path) -- all equal to zlib / the plaintext, in a child process (PZG_LIB)."""
+    import sys
+    from test_exotic_streams import NOTHREADS_FLAGS, lab_library
+    so = lab_library("nothreads", NOTHREADS_FLAGS)
+    code = r'''
+import os, sys, zlib
+sys.path.insert(0, os.path.join(os.environ["PZG_ROOT"], "tests")); sys.path.insert(0, os.environ["PZG_ROOT"])
+import numpy as np
+import torch; torch.cuda.init()
+import corpus
+import pure_zlib_amd as P
+from pure_zlib_amd import _ffi
+from pure_zlib_amd.zlib import PinnedArena
+assert _ffi.LIB_PATH.endswith("build/lab_nothreads/libpzg.so"), _ffi.LIB_PATH
+ctx = P.Context(0)
+texts = [corpus.zipf_text(1024 * (1 + (k * 37) % 48), k) for k in range(128)]
+zs = [zlib.compress(t, 6) for t in texts]
+n = 9000  # > 96 MiB: several pipelined ranges
+pick = np.random.default_rng(3).integers(0, len(zs), size=n)
+streams = [zs[k] for k in pick]
+streams[11] = streams[11][:-9]
+in_len = np.array([len(s) for s in streams], dtype=np.uint64)
+out_cap = np.array([len(texts[k]) for k in pick], dtype=np.uint64)
+in_off = np.concatenate([[0], np.cumsum((in_len[:-1] + 15) // 16 * 16)]).astype(np.uint64)
+out_off = np.concatenate([[0], np.cumsum((out_cap[:-1] + 15) // 16 * 16)]).astype(np.uint64)
+h_in = np.zeros(int(in_off[-1] + in_len[-1]) + 16, dtype=np.uint8)
+for k, s in enumerate(streams):
+    h_in[int(in_off[k]):int(in_off[k]) + len(s)] = np.frombuffer(s, dtype=np.uint8)
+for pinned in (False, True):
+    if pinned:
+        a_in, a_out = PinnedArena(h_in.size), PinnedArena(int(out_off[-1] + out_cap[-1]) + 16)
+        a_in.a[:] = h_in; src, dst = a_in.a, a_out.a
+    else:
+        src, dst = h_in, np.zeros(int(out_off[-1] + out_cap[-1]) + 16, dtype=np.uint8)
+    dst[:] = 0xCD
+    o_len, o_st, det, used, ad = ctx.decompress_many_raw(src, in_off, in_len, dst, out_off, out_cap, pinned=pinned)
+    assert o_st[11] == 1 and int((o_st == 0).sum()) == n - 1, (pinned, int((o_st != 0).sum()))
+    for k in range(n):
+        if k != 11:
+            assert dst[int(out_off[k]):int(out_off[k]) + int(out_cap[k])].tobytes() == texts[pick[k]], (pinned, k)
+from pure_zlib_amd import benchmark as HB
+plain = [corpus.zipf_text(128 * 1024, 9000 + k) for k in range(8)]
+res = HB.incremental_throughput(ctx, [zlib.compress(t, 6) for t in plain], plain, n_decoders=600, passes=1)
+assert res["ok"], res
+ctx.close()
+print("no-thread host paths ok", n, res["feed_calls"])
+'''
+    env = dict(os.environ, PZG_LIB=so, PZG_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "no-thread host paths ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_decompress_many_sharded_device_pointers(gpu_ctx, oracle, monkeypatch):
     """pzg_decompress_many_sharded (VERDICT r2 item 7): data ALREADY on the devices -- one batch of device pointers per
     shard, every batch enqueued on its own device's stream by one call, nothing staged through the host.  Three shards
