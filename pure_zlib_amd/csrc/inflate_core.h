@@ -354,7 +354,9 @@ struct BitReader {
     PZG_FN uint32_t take_prefetch() const
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t v = pf[lane_id()];
+        uint32_t l = lane_id();
+        asm volatile("" : "+v"(l));  // (opaque: or 4 * lane, as a 64-bit offset, is computed in the kernel's prologue and kept -- in the gzip instance: spilled -- for its whole life)
+        const uint32_t v = pf[l];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the buffer is free again before the next fetch is issued
         return v;
     }

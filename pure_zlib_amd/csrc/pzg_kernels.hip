@@ -23,10 +23,11 @@ namespace pzg {
 #ifndef PZG_MIN_WAVES_11
 #define PZG_MIN_WAVES_11 7
 #endif
-// (the gzip instance of ring 11 needs more vector registers than the zlib one: five waves per SIMD, 20 stream-waves per CU
-// instead of 26 -- with the strips the kernels' speed levels off at ~20 per CU anyway -- and nothing in scratch)
+// (the gzip instance of ring 11 needs more vector registers than the zlib one: 80, six waves per SIMD, 24 stream-waves per CU
+// instead of 26 -- round 5, once the prefetch pick-up's 4 * lane no longer lived in a register pair for the kernel's whole
+// life; rounds 3-4: 96 registers, five waves -- and nothing in scratch)
 #ifndef PZG_MIN_WAVES_11_GZIP
-#define PZG_MIN_WAVES_11_GZIP 5
+#define PZG_MIN_WAVES_11_GZIP 6
 #endif
 constexpr int waves_per_simd(int ring_bits, bool gzip = false)
 {

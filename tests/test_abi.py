@@ -65,16 +65,12 @@ def test_ring11_kernels_use_no_scratch():
     assert len(ring11) == 2, sorted(kernels)  # zlib and gzip
     for name, k in kernels.items():
         if "inflate_kernelILi1" in name:  # every ring size class, zlib and gzip, and the fixup instances
-            # (round 5: the zlib instance of ring 11 -- 72 registers, seven waves per SIMD -- parks ONE value in scratch where a block's
-            # token loop enters the strips and fetches it back on four rare paths; nothing in any loop, checked in the assembly
-            # (tests/tools/asm11.sh).  At 80 registers it parks none and runs 1-4 % slower: six waves per SIMD.)
-            allowed = (2, 8) if "inflate_kernelILi11ELb0ELb0E" in name else (0, 0)
-            assert k["vgpr_spill_count"] <= allowed[0] and k["private_segment_fixed_size"] <= allowed[1], (name, k)
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
     for name, k in ring11.items():
         # (round 4: strip_span() keeps ~30 more wave-uniform values alive beside the decoder's state -- 128 -> 256; round 5: the
         # groups' masks are scalar pairs -- 288)
         assert k["sgpr_spill_count"] <= 288, (name, k["sgpr_spill_count"])
-        assert k["vgpr_count"] <= (96 if "Lb0ELb1E" in name else 72), (name, k["vgpr_count"])  # gzip 5, zlib 7 waves per SIMD by registers
+        assert k["vgpr_count"] <= (80 if "Lb0ELb1E" in name else 72), (name, k["vgpr_count"])  # gzip 6, zlib 7 waves per SIMD by registers
         assert k["group_segment_fixed_size"] <= 6144, name  # 26 stream-waves per CU
 
 
