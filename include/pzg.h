@@ -177,7 +177,7 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
  *   default: no bound).  A launch's stream-waves decode long runs of input through a scratch of 64.5 KiB each -- 419 MiB for a
  *   launch that fills an MI355X (6,656 stream-waves) -- and a context keeps up to six such arenas per device, grow-only: two for
  *   device-pointer launches (overlapping launches must not share one) and one per host-path pipeline (four), 2.5 GiB at the
- *   most.  With a bound every arena gets an even share (bound / 6): only as many stream-waves as fit own a slice, the others
+ *   most; a pzg_decoder object keeps one more for its feeds (at most 4,096 stream-waves: 258 MiB).  With a bound every arena gets an even share (bound / 6): only as many stream-waves as fit own a slice, the others
  *   decode by the slower path that needs no scratch; below 64.5 KiB per arena all of them do.  Results never depend on it.
  *   Takes effect launch by launch (an arena larger than its share is released when it is next used). */
 #define PZG_OPT_SCRATCH_BYTES 3

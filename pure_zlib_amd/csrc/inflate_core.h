@@ -2062,7 +2062,9 @@ struct Decoder {
     // gives every LANE one whole SEQUENCE -- round 4's segments gave every lane one output BYTE and paid a prefix scan, two
     // crossbar scatters and two byte gathers per ~100 bytes: 2.3 wave-instructions per output byte, 77 % of a stream's time.
     // A group of up to 64 sequences (~500 bytes of text) costs one prefix sum, and the bytes move as unaligned dwords.
-    static constexpr bool STRIPS = !RES;
+    // (round 5: the resumable instance takes them too -- a span is decoded and emitted inside ONE call: it is cut behind the last lane
+    // whose output still fits the call's room, its far matches read the decoder's history, and the reference's chunk count is kept)
+    static constexpr bool STRIPS = true;
 #ifndef PZG_STRIP_TMAX
 #define PZG_STRIP_TMAX 192  // (round 4, measured on text / html / mixed / literal-heavy / config 3: 128: 249 / 237 / 260 / 128 / 141 GiB/s; 160: 260 / 242 /
                             // 269 / 123 / 139; 192: 263 / 241 / 272 / 134 / 141; 224: 261 / 243 / 277 / 127 / 138; 256: 260 / 247 / 277 / 120 / 141)
@@ -2325,6 +2327,7 @@ struct Decoder {
     // what a lane of phase B has produced so far
     struct SeqOut {
         LaneVec<uint32_t> STF;           // 1 = met a stopper
+        LaneVec<uint32_t> OB;            // (resumable instance) the output bytes of the lane's tokens
         LaneVec<uint32_t> NR, NLB, LR;   // records / literal bytes produced; literals since the last record
         LaneVec<uint32_t> REC[SEQ_G];    // the last records, REC[SEQ_G - 1] the newest
         LaneVec<uint32_t> LA[4];         // the last 16 literal bytes, the newest in the top byte of LA[3]
@@ -2360,6 +2363,7 @@ struct Decoder {
             const bool ok = act & !stop;
             PZG_LV(o.STF, k) = (act & stop) ? 1u : PZG_LV(o.STF, k);
             const bool is_m = ok & ((int32_t)tk < 0), is_l = ok & ((int32_t)tk >= 0);
+            if (RES) PZG_LV(o.OB, k) += ok ? (tk >> 16) & 511u : 0u;
             // a literal: its byte enters the 16-byte accumulator from the top (a funnel shift by 8 or by nothing: no selects)
             const uint32_t sh = is_l ? 8u : 0u;
             PZG_LV(o.LA[0], k) = funnel(PZG_LV(o.LA[1], k), PZG_LV(o.LA[0], k), sh);
@@ -2482,6 +2486,7 @@ struct Decoder {
             PZG_LV(S, k) = PZG_LV(P, k);
             PZG_LV(LIM, k) += C;
             PZG_LV(o.STF, k) = 0u;
+            PZG_LV(o.OB, k) = 0u;
             PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
 #pragma unroll
             for (uint32_t g = 0; g < SEQ_G; ++g) PZG_LV(o.REC[g], k) = 0u;
@@ -2499,6 +2504,7 @@ struct Decoder {
                         const uint32_t p = PZG_LV(S, k);
                         PZG_LV(P, k) = p;
                         PZG_LV(o.STF, k) = 0u;
+                        PZG_LV(o.OB, k) = 0u;
                         PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
                         strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
                     }
@@ -2543,6 +2549,26 @@ struct Decoder {
             // (input on which the run-ups do not find the chain -- none of the corpora has such a span -- would pay six rounds for
             // a few strips every time: the rest of the block is left to the windows)
             if (last < 16u) poor = true;
+        }
+        if (RES) {  // never produce past this call's room: the span ends behind the last lane whose output still fits
+            LaneVec<uint32_t> OBS;
+            LaneVec<bool> FITS;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(OBS, k) = k <= last ? PZG_LV(o.OB, k) : 0u;
+            PZG_LANES_END
+            lanes_iscan_add(OBS);
+            const uint64_t room64 = cap > op + 1024u ? cap - op - 1024u : 0u;
+            const uint32_t room = room64 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)room64;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(FITS, k) = PZG_LV(OBS, k) <= room;
+            PZG_LANES_END
+            const uint64_t fits = lanes_ballot(FITS);  // (the sums grow with the lane: ones, then zeros)
+            const uint32_t kfit = fits == ~0ull ? 64u : ctz64(~fits);
+            if (kfit == 0u) return STRIP_NA;  // (nothing has moved: the windows produce what still fits and report the full room)
+            if (kfit <= last) {
+                last = kfit - 1u;
+                stopm = 0ull;
+            }
         }
         stopper = stopm != 0ull && lane_get(o.STF, last) == 1u;
         const uint32_t pend = lane_get(P, last);
@@ -2751,12 +2777,30 @@ struct Decoder {
         lds_put_bytes(A, X, m, m, m, m);
 #endif
     }
+    // Where produced byte op + rel (rel < 0: older than the ring, flushed) lies, as an offset from far_base: in the stream's own
+    // output -- or, for a resumable decoder on a small ring, in its 32 KiB history, by position modulo its size.
+    PZG_FN uint32_t far_off(uint32_t op32, uint32_t fdelta, uint32_t rel) const
+    {
+        return RES_HIST ? (op32 + rel) & HIST_MASK : 32768u + fdelta + rel;
+    }
     PZG_FN uint32_t far_load32(uint32_t off) const
     {
+#if PZG_DEVICE_PASS
+        if (RES_HIST)  // (the history is rewritten as the stream goes: past the L1)
+            return __hip_atomic_load(reinterpret_cast<const uint32_t *>(far_base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         uint32_t v;
         __builtin_memcpy(&v, far_base + off, 4);
         return v;
     }
+    PZG_FN uint8_t far_load8(uint32_t off) const
+    {
+#if PZG_DEVICE_PASS
+        if (RES_HIST) return __hip_atomic_load(far_base + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        return far_base[off];
+    }
+    static constexpr uint32_t FAR_DUMMY = RES_HIST ? 0u : FAR_IDLE;  // what a lane with no far source reads
     // The group's near matches: where they read (SM) and write (DM) in the ring, and the lanes that move dwords (norm4: four
     // bytes or more, NB whole quads from the front and one that ENDS with the match, ST -> DT -- it overlaps the one before it
     // instead of a tail of single bytes), three bytes (norm3), or go byte by byte (slow: a run that wraps around the ring's end,
@@ -2904,21 +2948,30 @@ struct Decoder {
         // ---- the far matches' sources: asked for.  They end SEQ_GLIM + ... bytes below `flushed` at the least (static_assert
         // above), in lines that are complete and final (see set_far_base).
         LaneVec<uint32_t> FO, FND, FX[4];
-        const uint64_t farn = farm & ~wrapd, fars = farm & wrapd;
+        uint64_t farn = farm & ~wrapd, fars = farm & wrapd;
         if (HYBRID && farm != 0ull) {
             PZG_STAT(25, 1);
             far_fence();
             const uint32_t fdelta = (uint32_t)(op - flushed);
+            if (RES_HIST) {  // (a source that wraps around the history's end: byte by byte)
+                LaneVec<bool> HW;
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(HW, j) = far_off(op32, fdelta, PZG_LV(MO, j) - PZG_LV(DIST, j)) + PZG_LV(c.LEN, j) + 3u > HIST_BYTES;
+                PZG_LANES_END
+                const uint64_t hw = lanes_ballot(HW);
+                fars = farm & (wrapd | hw);
+                farn = farm & ~(wrapd | hw);
+            }
             PZG_LANES_BEGIN(j)
                 const uint32_t len = PZG_LV(c.LEN, j), l4 = len >= 4u ? len - 4u : 0u;
-                const uint32_t nd = mask_keep(farn, j, (len + 3u) >> 2), fo = 32768u + fdelta + PZG_LV(MO, j) - PZG_LV(DIST, j);  // the source's first byte, from far_base
+                const uint32_t nd = mask_keep(farn, j, (len + 3u) >> 2), fo = far_off(op32, fdelta, PZG_LV(MO, j) - PZG_LV(DIST, j));  // the source's first byte, from far_base
                 PZG_LV(FND, j) = nd;
                 PZG_LV(FO, j) = fo;
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     const uint32_t off = 4u * u < l4 ? 4u * u : l4;
 #if PZG_DEVICE_PASS
-                    PZG_LV(FX[u], j) = far_load32(u < nd ? fo + off : FAR_IDLE);
+                    PZG_LV(FX[u], j) = far_load32(u < nd ? fo + off : FAR_DUMMY);
 #else
                     PZG_LV(FX[u], j) = u < nd ? far_load32(fo + off) : 0u;
 #endif
@@ -3081,7 +3134,7 @@ struct Decoder {
                     for (uint32_t u = 0; u < 4u; ++u) {
                         const uint32_t off = 4u * (i0 + u) < l4 ? 4u * (i0 + u) : l4;
 #if PZG_DEVICE_PASS
-                        PZG_LV(FX[u], j) = far_load32(PZG_LV(FA[u], j) ? PZG_LV(FO, j) + off : FAR_IDLE);
+                        PZG_LV(FX[u], j) = far_load32(PZG_LV(FA[u], j) ? PZG_LV(FO, j) + off : FAR_DUMMY);
 #else
                         PZG_LV(FX[u], j) = PZG_LV(FA[u], j) ? far_load32(PZG_LV(FO, j) + off) : 0u;
 #endif
@@ -3097,10 +3150,11 @@ struct Decoder {
                     const uint64_t a0 = fars & lanes_ballot(A0);
                     if (a0 == 0ull) break;
                     PZG_LANES_BEGIN(j)
+                        const uint32_t fb = RES_HIST ? (PZG_LV(FO, j) + i) & HIST_MASK : PZG_LV(FO, j) + i;
 #if PZG_DEVICE_PASS
-                        const uint8_t b = far_base[mask_select(a0, j, PZG_LV(FO, j) + i, FAR_IDLE)];
+                        const uint8_t b = far_load8(mask_select(a0, j, fb, FAR_DUMMY));
 #else
-                        const uint8_t b = lane_bit(a0, j) ? far_base[PZG_LV(FO, j) + i] : (uint8_t)0;
+                        const uint8_t b = lane_bit(a0, j) ? far_load8(fb) : (uint8_t)0;
 #endif
                         ring_store(lane_bit(a0, j), (PZG_LV(c.DM, j) + i) & RMASK, b, j);
                     PZG_LANES_END
@@ -3130,6 +3184,21 @@ struct Decoder {
             PZG_STAT(23, 1);
         }
         PZG_MARK("g.end");
+        if (RES) {
+            // The reference hands out one 32 KiB chunk when its window holds 64 KiB or more, looked at after every MATCH
+            // (account_tokens): in a group that is the first match that ends at or behind the mark -- at most one: the window
+            // then holds less again for the rest of the group's <= SEQ_GLIM bytes.
+            LaneVec<bool> FIRE;
+            PZG_LANES_BEGIN(j)
+                PZG_LV(FIRE, j) = ow + (PZG_LV(ENDX, j) & 0xffffu) >= 65536u;
+            PZG_LANES_END
+            const uint64_t fire = lanes_ballot(FIRE) & hasm;
+            ow += run;
+            if (fire != 0ull) {
+                ow -= 32768u;
+                chunks += 1u;
+            }
+        }
         op += run;
         PZG_SEQ_ACC(6, tq);
         return SQ_OK;
@@ -3172,9 +3241,9 @@ struct Decoder {
                     if (ballot(far) & far_okmask) {
                         far_fence();
 #if PZG_DEVICE_PASS
-                        const uint8_t fb = far_base[far ? 32768u + fdelta + m + off - dist : FAR_IDLE];
+                        const uint8_t fb = far_load8(far ? far_off(op32, fdelta, m + off - dist) : FAR_DUMMY);
 #else
-                        const uint8_t fb = far ? far_base[32768u + fdelta + m + off - dist] : (uint8_t)0;
+                        const uint8_t fb = far ? far_load8(far_off(op32, fdelta, m + off - dist)) : (uint8_t)0;
 #endif
                         v[c] = far ? fb : v[c];
                     }
@@ -3214,6 +3283,7 @@ struct Decoder {
             ring_store(i < nl, ((uint32_t)op + i) & RMASK, b, lane);
         }
         op += nl;
+        if (RES) ow += nl;  // (no match: no moveWindow check)
         maybe_flush();
         if (len != 0u) {
             if ((uint64_t)dist > op + (RING_BITS == 15 ? hist_extra : 0u)) return fail(ST_BAD_DISTANCE, dist, (uint32_t)op);
@@ -3222,6 +3292,7 @@ struct Decoder {
 #endif
             copy_match(dist, len);
             maybe_flush();
+            if (RES) account_tokens(len, 1u, true);
         }
         s_lc += nl;
         s_rd += 1u;
@@ -3835,8 +3906,22 @@ struct Decoder {
     PZG_FN int token_loop_res()
     {
         if (deferred != 0u) susp_pos = stream_bit_pos();  // (resumed while draining: nothing of this call's input is consumed yet)
+        bool strips = STRIPS && strip != nullptr;
         for (;;) {
             int st;
+            bool span_stopper = false;
+            if (deferred == 0u && strips) {
+                // (round 5) a span of strips while the call's input and room have space for one: decoded and emitted inside this call
+                bool poor = false;
+                const int ss = strip_span<false>(span_stopper, poor);
+                if (ss == ST_OUT_FULL) {
+                    susp_pos = stream_bit_pos();
+                    return ST_OUT_FULL;
+                }
+                if (ss != ST_OK && ss != STRIP_NA) return ss;
+                if (ss == STRIP_NA || poor) strips = false;
+                if (ss == ST_OK && !span_stopper) continue;
+            }
             if (deferred == 0u) {
                 // (round 4: the resumable decoder runs the same hot loop as the batch kernel for as long as whole 128-bit
                 // windows lie inside this call's input and nothing special is due; everything else -- the end of the input,
@@ -3844,9 +3929,9 @@ struct Decoder {
                 LaneVec<uint32_t> TK0, TK1;
                 uint64_t S0 = 0, S1 = 0;
                 uint32_t k0 = 0, k1 = 0;
-                const uint32_t why = PZG_RES_HOT_LOOP ? (use_sub ? hot_loop<false, 1>(TK0, TK1, S0, S1, k0, k1) : hot_loop<false, 0>(TK0, TK1, S0, S1, k0, k1))
-                                                      : (uint32_t)HL_GENERAL;
-                const bool checked = why == HL_WINDOW ? window2_rare(TK0, TK1, S0, S1, k0, k1) : (qn < QHIGH && fill_queue<false>());
+                const uint32_t why = (PZG_RES_HOT_LOOP && !span_stopper) ? (use_sub ? hot_loop<false, 1>(TK0, TK1, S0, S1, k0, k1) : hot_loop<false, 0>(TK0, TK1, S0, S1, k0, k1))
+                                                                          : (uint32_t)HL_GENERAL;
+                const bool checked = span_stopper || (why == HL_WINDOW ? window2_rare(TK0, TK1, S0, S1, k0, k1) : (qn < QHIGH && fill_queue<false>()));
                 if (!checked) {
                     const int se = emit_segment();
                     if (se == ST_OUT_FULL) {

@@ -1248,6 +1248,7 @@ struct pzg_decoder {
     uint8_t *d_state = nullptr;  // n x stride: ResumeState + LDS image per decoder
     uint32_t *d_counter = nullptr;
     Arena d_in, d_out, d_meta, d_dense, d_doff;
+    Arena d_strip;  // the resume kernels' scratch (round 5: spans of strips inside a feed): a slice per stream-wave of a feed's launches
     Pinned h_in, h_out, h_meta, h_doff;  // page-locked staging (grow-only): the copies run at link speed and really are asynchronous
     hipStream_t stream = nullptr;
     // a large feed is cut into ranges of decoders that overlap their uploads, launches, downloads and host copies
@@ -1327,7 +1328,7 @@ void pzg_decoder_destroy(pzg_decoder *dec)
         if (st) (void)hipStreamSynchronize(st);
     for (hipStream_t st : dec->s_kr)
         if (st) (void)hipStreamSynchronize(st);
-    for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta, &dec->d_dense, &dec->d_doff})
+    for (Arena *a : {&dec->d_in, &dec->d_out, &dec->d_meta, &dec->d_dense, &dec->d_doff, &dec->d_strip})
         if (a->p) (void)hipFree(a->p);
     for (Pinned *h : {&dec->h_in, &dec->h_out, &dec->h_meta, &dec->h_doff}) pinned_release(*h);
     if (dec->d_state) (void)hipFree(dec->d_state);
@@ -1432,6 +1433,40 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
         a.counter = dec->d_counter;
         // one launch per run of consecutive decoder numbers among positions [j0, j1) of the call
         uint64_t *dense_host = nullptr;  // (set by the pipelined path when the kernels write their results into host memory)
+        // The kernels' scratch: one slice per stream-wave of this feed's launches -- at most the chip's residency, at most an arena's
+        // share of PZG_OPT_SCRATCH_BYTES; a feed that gets none (or fewer slices than waves) decodes those waves by windows alone.
+        // Launches that may run side by side (the ranges of a large feed) get disjoint runs of slices.
+        uint32_t strip_slices = 0;
+        {
+            const size_t per_wave = pzg::resume_strip_wave_bytes();
+            size_t want = (size_t)pzg::resume_launch_waves(num_cus, m) * per_wave;
+            const uint64_t capb = ctx->scratch_cap.load();
+            if (capb != 0) {
+                const size_t share = (size_t)(capb / (uint64_t)(STRIP_SLOTS + LANES_PER_SHARD)) / per_wave * per_wave;
+                if (want > share) want = share;
+                if (dec->d_strip.cap > share + 255u) {
+                    (void)hipFree(dec->d_strip.p);
+                    dec->d_strip.p = nullptr;
+                    dec->d_strip.cap = 0;
+                }
+            }
+            if (want >= per_wave) {
+                if (dec->d_strip.cap < want) {
+                    if (dec->d_strip.p) (void)hipFree(dec->d_strip.p);
+                    dec->d_strip.p = nullptr;
+                    dec->d_strip.cap = 0;
+                    void *q = nullptr;
+                    if (hipMalloc(&q, (want + 255u) & ~(size_t)255u) == hipSuccess) {
+                        dec->d_strip.p = q;
+                        dec->d_strip.cap = (want + 255u) & ~(size_t)255u;
+                    } else {
+                        (void)hipGetLastError();  // (tolerated: windows alone)
+                    }
+                }
+                if (dec->d_strip.p) strip_slices = (uint32_t)(want / per_wave);
+            }
+        }
+        uint32_t strip_lo = 0, strip_n = strip_slices;  // the run of slices the next launch_runs() call may use
         auto launch_runs = [&](uint32_t j0, uint32_t jend, uint32_t *counter, hipStream_t st, uint64_t dense_region = 0, uint32_t *dense_cursor = nullptr) -> hipError_t {
             if (dense_cursor) {
                 const hipError_t e = hipMemsetAsync(dense_cursor, 0, sizeof(uint32_t), st);
@@ -1458,6 +1493,10 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                 r.final_in += j0;
                 r.n = j1 - j0;
                 r.counter = counter;
+                if (strip_n != 0) {  // (the runs of one call go to one stream, one after the other: they share their slices)
+                    r.strip = (uint32_t *)((uint8_t *)dec->d_strip.p + (size_t)strip_lo * pzg::resume_strip_wave_bytes());
+                    r.strip_waves = strip_n;
+                }
                 if (dense_cursor) {
                     r.dense = (uint8_t *)dec->d_dense.p;
                     r.dense_region = dense_region;
@@ -1669,6 +1708,8 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                     FEED_TRY(hipStreamWaitEvent(s_k, dec->ev_up[c], 0));
                     // (a counter word, a packing cursor and a stream of its own per range: the launches overlap; the range's packed region
                     // starts where its rooms start)
+                    strip_lo = (uint32_t)((uint64_t)strip_slices * j0 / m);  // (ranges run side by side: each its own slices)
+                    strip_n = (uint32_t)((uint64_t)strip_slices * j1 / m) - strip_lo;
                     FEED_TRY(launch_runs(j0, j1, dec->d_counter + 8u * c, s_k, ooff[j0], dec->d_counter + 8u * c + 1u));
                     FEED_TRY(hipEventRecord(dec->ev_k[c], s_k));
                     if (direct) {

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(64, RES_RING == 15 ? 1 : PZG_RES_WAVES_PER_SIMD) vo
         ResumeState *rs = (ResumeState *)slot;
         uint32_t *image = (uint32_t *)(slot + ResumeSlot<RES_RING>::IMAGE_OFF);
         Decoder<RES_RING, false, true> dec(lds);
+        if (a.strip && blockIdx.x < a.strip_waves) dec.strip = a.strip + (size_t)blockIdx.x * Decoder<RES_RING, false, true>::STRIP_WORDS;
         StreamResult r;
         uint32_t chunks = 0;
         dec.run_resume(rs, image, slot + ResumeSlot<RES_RING>::HIST_OFF, a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i],
@@ -189,16 +190,21 @@ __global__ __launch_bounds__(64, RES_RING == 15 ? 1 : PZG_RES_WAVES_PER_SIMD) vo
 size_t resume_scalar_bytes() { return sizeof(ResumeState); }
 size_t resume_state_bytes() { return ResumeSlot<RES_RING>::BYTES; }
 
+size_t resume_strip_wave_bytes() { return (size_t)Decoder<RES_RING, false, true>::STRIP_WORDS * sizeof(uint32_t); }
+uint32_t resume_launch_waves(int num_cus, uint32_t n)
+{
+    constexpr uint32_t by_lds = (160u * 1024u) / (uint32_t)((sizeof(WaveLds<RES_RING>) + 511u) / 512u * 512u);
+    constexpr uint32_t by_vgpr = RES_RING == 15 ? 4u : 4u * PZG_RES_WAVES_PER_SIMD;
+    const uint32_t waves = (uint32_t)num_cus * (by_lds < by_vgpr ? by_lds : by_vgpr);
+    return waves > n ? n : waves;
+}
+
 hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    constexpr uint32_t by_lds = (160u * 1024u) / (uint32_t)((sizeof(WaveLds<RES_RING>) + 511u) / 512u * 512u);
-    constexpr uint32_t by_vgpr = RES_RING == 15 ? 4u : 4u * PZG_RES_WAVES_PER_SIMD;
-    uint32_t waves = (uint32_t)num_cus * (by_lds < by_vgpr ? by_lds : by_vgpr);
-    if (waves > a.n) waves = a.n;
-    hipLaunchKernelGGL(inflate_resume_kernel, dim3(waves), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(inflate_resume_kernel, dim3(resume_launch_waves(num_cus, a.n)), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -58,10 +58,16 @@ struct ResumeArgs {
     uint64_t dense_region;
     uint32_t *dense_cursor;  // zeroed by the launcher's caller; counts 16-byte units
     uint64_t *dense_off;     // n
+    // the stream-waves' scratch (inflate_core.h strip_span), resume_strip_wave_bytes() per wave, or null: workgroups 0 .. strip_waves - 1
+    // own a slice, the others -- and all of them without it -- decode by windows alone.  Not shared with a launch that may run at the same time.
+    uint32_t *strip;
+    uint32_t strip_waves;
 };
 hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream);
 size_t resume_state_bytes();   // one decoder's slot: ResumeState + LDS image
 size_t resume_scalar_bytes();  // ... its ResumeState part (zeroing it makes the decoder fresh)
+size_t resume_strip_wave_bytes();                      // one stream-wave's slice of ResumeArgs::strip
+uint32_t resume_launch_waves(int num_cus, uint32_t n);  // workgroups of a launch over n decoders
 
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);
 size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip);  // what InflateArgs::strip holds when every stream-wave of that launch owns a slice

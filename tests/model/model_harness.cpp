@@ -79,6 +79,10 @@ static int resume_feed(uint8_t *state, const uint8_t *in, uint64_t in_len, uint3
     if (in_len) memcpy(buf + 8, in, in_len);
     pzg::Decoder<RB, false, true> dec(*lds);
     pzg::StreamResult sr;
+    // the wave's scratch (strips), as in run_one(); PZM_NO_STRIPS=1: the windows alone
+    uint32_t *strip = getenv("PZM_NO_STRIPS") ? nullptr : (uint32_t *)malloc(sizeof(uint32_t) * pzg::Decoder<RB, false, true>::STRIP_WORDS);
+    if (strip) memset(strip, 0xC3, sizeof(uint32_t) * pzg::Decoder<RB, false, true>::STRIP_WORDS);
+    dec.strip = strip;
     dec.run_resume((pzg::ResumeState *)state, (uint32_t *)(state + pzg::ResumeSlot<RB>::IMAGE_OFF), state + pzg::ResumeSlot<RB>::HIST_OFF, buf + 8,
                    in_len, out, cap, final_input, &sr, chunks);
     r->status = sr.status;
@@ -87,6 +91,7 @@ static int resume_feed(uint8_t *state, const uint8_t *in, uint64_t in_len, uint3
     r->adler = sr.adler;
     r->out_len = sr.out_len;
     r->in_used = sr.in_used;
+    free(strip);
     free(buf);
     free(lds);
     return 0;

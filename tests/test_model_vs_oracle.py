@@ -283,6 +283,35 @@ def test_model_incremental_event_trace(model_lib, oracle, rb):
             assert bytes(dec.total) == oo
 
 
+@pytest.mark.parametrize("rb", [12, 15])
+def test_model_incremental_spans_of_strips(model_lib, oracle, rb):
+    """Round 5: the resumable decoder takes the strips too -- a span is decoded and emitted inside one call, cut behind the last lane
+    whose output still fits the call's room, its far matches read the decoder's history, the reference's chunk count is kept group by
+    group.  The bench's shape (256 KiB of text in 32 KiB pieces, 192 KiB rooms), rooms that cut spans short (24 KiB, 9 KiB), a piece
+    size that leaves tails for the windows, writer-made streams (tests/deflate_writer.py) and corrupted ones: whole event traces and
+    every byte against the oracle's."""
+    import deflate_writer as W
+    cases = []
+    for seed in range(3):
+        z = zlib.compress(corpus.zipf_text(256 * 1024, 7000 + seed), 6)
+        cases += [(z, 32768, 192 * 1024), (z, 32768, 24 * 1024), (z, 20000, 9 * 1024)]
+    for seed in (0, 3, 5, 7):
+        d, z, _ = W.exotic_stream(seed)
+        cases += [(z, 32768, 70000), (corpus.corrupt(z, seed), 16000, 40000)]
+    z = zlib.compress(corpus.html_slice(60000, 1) + corpus.skewed_bytes(90000, 2), 6)
+    cases += [(z, 50000, 100000), (corpus.corrupt(z, 5), 50000, 100000)]
+    for k, (z, step, room) in enumerate(cases):
+        pieces = [z[i:i + step] for i in range(0, len(z), step)]
+        eo, ro, oo = oracle.trace(pieces)
+        dec = ModelDecoder(model_lib, room, rb)
+        for p in pieces:
+            if not dec.feed(p):
+                break
+        assert dec.events == eo, (k, len(z), step, room, ro.status)
+        if ro.status == 0:
+            assert bytes(dec.total) == oo
+
+
 def test_model_incremental_bad_header_with_fdict_bit(model_lib, oracle):
     """Zlib.hs:53-67: CMF and FLG are read and checked (FCHECK, method, window) before anything else; a bad header whose FDICT
     bit is set is a DecompError after two bytes, not a NeedMore waiting for a DICTID."""
