@@ -79,6 +79,61 @@ def test_event_trace_seeded_streams_late_errors_small_rooms(gpu_ctx, oracle):
             assert isinstance(err, Z.DecompressionError)
 
 
+def test_event_trace_spans_of_strips_and_the_scratch_cap(gpu_ctx, oracle):
+    """Round 5: the resumable kernel decodes by strips too (a span inside one call, cut to the call's room, far matches from the
+    decoder's history, the reference's chunk count kept per group).  The bench's shape (256 KiB of text in 32 KiB pieces, 192 KiB
+    rooms), rooms that cut spans short, writer-made streams (tests/deflate_writer.py), html + literal-heavy data and corrupted
+    variants -- 24 decoders fed in lockstep, one launch per feed -- with the library's scratch unlimited, capped at 32 MiB
+    (PZG_OPT_SCRATCH_BYTES: some stream-waves get no slice) and withheld altogether (a 1-byte cap: the windows alone): the same
+    event traces and bytes as the oracle every time."""
+    import deflate_writer as W
+    from pure_zlib_amd.incremental import Chunk, DecoderPool, DecompError, Done, NeedMore
+    zs = []
+    for seed in range(8):
+        zs.append(zlib.compress(corpus.zipf_text(256 * 1024, 7000 + seed), 6))
+    for seed in (0, 1, 3, 5, 6, 7):
+        z = W.exotic_stream(seed)[1]
+        zs += [z, corpus.corrupt(z, seed)]
+    z = zlib.compress(corpus.html_slice(60000, 1) + corpus.skewed_bytes(90000, 2), 6)
+    zs += [z, corpus.corrupt(z, 5), zlib.compress(corpus.mixed_data(300000, 4), 9), zlib.compress(corpus.zipf_text(100000, 3), 1)]
+    n = len(zs)
+    try:
+        for cap, step, room in ((0, 32768, 192 * 1024), (32 << 20, 32768, 24 * 1024), (1, 20000, 70000), (0, 50000, 9 * 1024)):
+            gpu_ctx.set_scratch_bytes(cap)
+            pool = DecoderPool(n, gpu_ctx, room=room)
+            events = [[("NeedMore",)] for _ in range(n)]
+            got = [bytearray() for _ in range(n)]
+            live, pos = list(range(n)), 0
+            while live:
+                sts = pool.feed(live, [zs[k][pos:pos + step] for k in live])
+                nxt = []
+                for k, st in zip(live, sts):
+                    while isinstance(st, Chunk):
+                        events[k].append(("Chunk", len(st.chunk)))
+                        got[k] += st.chunk
+                        st = st.next()
+                    if isinstance(st, NeedMore):
+                        events[k].append(("NeedMore",))
+                        if pos + step < len(zs[k]):
+                            nxt.append(k)
+                    elif isinstance(st, Done):
+                        events[k].append(("Done",))
+                    else:
+                        assert isinstance(st, DecompError)
+                        events[k].append(("DecompError", st.error.status))
+                live = nxt
+                pos += step
+            pool.close()
+            for k in range(n):
+                pieces = [zs[k][i:i + step] for i in range(0, len(zs[k]), step)]
+                eo, ro, oo = oracle.trace(pieces)
+                assert events[k] == eo, (cap, step, room, k, ro.status, events[k][-3:], eo[-3:])
+                if ro.status == 0:
+                    assert bytes(got[k]) == oo, (cap, step, room, k)
+    finally:
+        gpu_ctx.set_scratch_bytes(0)
+
+
 def test_many_decoders_per_launch(gpu_ctx, oracle):
     """64 decoders fed in lockstep, each launch continuing all that still want input: the traces stay the reference's."""
     from pure_zlib_amd.incremental import Chunk, DecoderPool, Done, NeedMore
