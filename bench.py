@@ -42,7 +42,7 @@ def kernel_sha256():
     """What the measured traffic belongs to: the kernels' source (profiles/traffic.json records it with every entry)."""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("inflate_core.h", "pzg_kernels.hip", "wave.h"):
+    for fn in ("inflate_core.h", "pzg_inflate_kernel.h", "pzg_kernels.hip", "pzg_kernels_b.hip", "wave.h"):
         with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()

@@ -2075,7 +2075,8 @@ struct Decoder {
     static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may decode per span (a multiple of 16)
     // (a strip of C <= STRIP_TMAX x the shortest code bits holds at most STRIP_TMAX tokens, so at most as many records and literal
     // bytes: a region cannot overflow, and a run of literals inside one strip cannot outgrow the record's eight-bit count)
-    static_assert(STRIP_TMAX % 16u == 0u && STRIP_TMAX <= 240u, "region geometry; a record counts up to 255 literals");
+    static_assert(STRIP_TMAX % 16u == 0u && STRIP_TMAX <= 1008u, "region geometry");
+    static constexpr bool SEQ_LROVF = STRIP_TMAX > 240u;  // a record counts up to 255 literals: a longer run is cut into records without a match
 #ifndef PZG_SEQ_GROUP
 #define PZG_SEQ_GROUP 8
 #endif
@@ -2085,8 +2086,24 @@ struct Decoder {
     static constexpr uint32_t SEQ_G = PZG_SEQ_GROUP;           // records per store (a power of two)
     static constexpr uint32_t REG_LITA = 32u;
     static constexpr uint32_t REG_RECA = (REG_LITA + STRIP_TMAX + 4u * SEQ_G + 31u) & ~31u;
-    static constexpr uint32_t REG_BYTES = (REG_RECA + 4u * STRIP_TMAX + 63u) & ~63u;
-    static constexpr uint32_t STRIP_WORDS = 64u * (REG_BYTES / 4u) + 128u;  // dwords of scratch per wave (+ what a refill may read past the end)
+#ifndef PZG_REG_PAD
+#define PZG_REG_PAD 0
+#endif
+    static constexpr uint32_t REG_BYTES = ((REG_RECA + 4u * STRIP_TMAX + 63u) & ~63u) + PZG_REG_PAD;
+    // (the regions | 128 dwords that a refill may read past their end | the wave's profile, see strip_profile_*)
+    static constexpr uint32_t PROF_OFF = 64u * (REG_BYTES / 4u) + 128u;
+    static constexpr uint32_t STRIP_WORDS = PROF_OFF + 80u;  // dwords of scratch per wave
+    static constexpr uint32_t PROF_MAGIC = 0x51DF0A7Eu;
+#ifndef PZG_STRIP_PROFILE
+#define PZG_STRIP_PROFILE 1
+#endif
+    static constexpr bool STRIP_PROFILE = PZG_STRIP_PROFILE != 0 && !RES;
+    static constexpr uint32_t PROF_TGT = STRIP_TMAX * 3u / 4u;  // tokens per lane that a span laid out by the profile aims at
+#ifndef PZG_PROF_CMIN
+#define PZG_PROF_CMIN 512
+#endif
+    static constexpr uint32_t PROF_CMIN = PZG_PROF_CMIN;        // ... and only streams with so many bits per lane have one
+    static constexpr uint32_t PROF_HEAD = 2048u;                // a span that starts within so many bits of the stream's start is "the first"
     static constexpr uint32_t STRIP_BACK = PZG_STRIP_BACK;      // the run-up of phase A, in bits: where a wave starts, and the most it uses
     // Round 5: the run-up ADAPTS.  How fast a wrong start falls back onto the real chain of tokens depends on the code: measured
     // with a fixed run-up of 256 / 384 / 512 / 768 bits, text 257 / 261 / 268 / 276 GiB/s and config 3 119 / 136 / 144 / 148 (a lane
@@ -2303,7 +2320,7 @@ struct Decoder {
     // One step of phase A for every lane still in its run-up; false: none is.  (T, PD: this step's landing register.)
     template <bool FX>
     PZG_FN bool strip_step_a(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, StripReader &rd, LaneVec<uint32_t> &P,
-                             const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
+                             const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD, LaneVec<uint32_t> &CNT)
     {
         LaneVec<bool> ACT;
         PZG_LANES_BEGIN(k)
@@ -2316,6 +2333,7 @@ struct Decoder {
             uint32_t tb, tk;
             strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk);
             const uint32_t adv = PZG_LV(ACT, k) ? (tb < 128u ? tb : 1u) : 0u;  // (no token here: this is not the chain yet)
+            PZG_LV(CNT, k) += PZG_LV(ACT, k) ? 1u : 0u;  // (the run-up's tokens: strip_profile_check)
             PZG_LV(P, k) += adv;
             PZG_SR(R) += adv;
             strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
@@ -2373,9 +2391,10 @@ struct Decoder {
             const uint32_t nlb = PZG_LV(o.NLB, k) + (is_l ? 1u : 0u), lr = PZG_LV(o.LR, k) + (is_l ? 1u : 0u);
             PZG_LV(o.NLB, k) = nlb;
             // a record: a match closes the sequence its literals opened
-            const bool emit = is_m;
+            const bool ovf = SEQ_LROVF && (is_l & (lr == 255u));  // (the record of a literal run that is full: no match, whatever its low bits say)
+            const bool emit = is_m | ovf;
             const uint32_t a = tk - 0x00030001u;  // (length - 3) << 16 | distance - 1: no borrow (distance >= 1)
-            const uint32_t rec = (a & 0x7fffu) | (((a >> 16) & 0xffu) << 15) | (lr << 23);
+            const uint32_t rec = (a & 0x7fffu) | (((a >> 16) & 0xffu) << 15) | (lr << 23) | (ovf ? SEQ_NOMATCH : 0u);
 #pragma unroll
             for (uint32_t g = 0; g + 1u < SEQ_G; ++g) PZG_LV(o.REC[g], k) = emit ? PZG_LV(o.REC[g + 1u], k) : PZG_LV(o.REC[g], k);
             PZG_LV(o.REC[SEQ_G - 1u], k) = emit ? rec : PZG_LV(o.REC[SEQ_G - 1u], k);
@@ -2426,24 +2445,281 @@ struct Decoder {
         PZG_LANES_END
     }
 
+    // ---- the wave's profile: strips of equal WORK ---------------------------------------------------------------------------
+    // Phase B takes as many steps as the strip with the most tokens has tokens, and equal strips are far from equal work: a
+    // stream's first tokens are literals (there is nothing to match yet) and its matches grow as the window fills -- measured on
+    // the 32 KiB text streams of the headline batch, 64 equal strips hold 232 tokens in the first and ~105 in the last (mean 131):
+    // the lanes of phase B were busy 56 % of the time.  How the tokens are spread over a stream is much the same from one stream
+    // of a batch to the next, so a wave REMEMBERS it: after the first span of a stream, the bit positions (from the span's start)
+    // at which 0/64, 1/64, ... 63/64 of the span's tokens had gone by -- 64 dwords, the span's extent, its token count and a
+    // magic word, in the wave's scratch (it outlives streams and launches like the wave's LDS does; there is no LDS left for it).
+    // The first span of the next stream cuts its strips at those positions (stretched or cut to the stream's own length; behind
+    // the profile's end the last density goes on), as long a span as PROF_TGT tokens per lane allow.  Nothing about the result
+    // depends on it (every lane's start is verified as before, a lane out of steps ends the span and forgets the profile); spans
+    // further into a stream, where the density is flat, keep equal strips.
+    // a / b, roughly (both below 2^27; b > 0): the profile needs no exact quotients
+    PZG_FN static uint32_t prof_div(uint32_t a, uint32_t b)
+    {
+#if PZG_DEVICE_PASS
+        return (uint32_t)((float)a * __builtin_amdgcn_rcpf((float)b));
+#else
+        return (uint32_t)((float)a / (float)b);
+#endif
+    }
+    // a constant that is not worth a register of its own for the kernel's whole life: these functions run once per stream, and
+    // what the compiler finds constant in them it would otherwise move to the kernel's first lines and keep (see take_prefetch)
+    PZG_FN static uint32_t prof_k(uint32_t c)
+    {
+#if PZG_DEVICE_PASS
+        asm volatile("" : "+s"(c));
+#endif
+        return c;
+    }
+    PZG_FN bool strip_profile_layout(uint64_t cav64, LaneVec<uint32_t> &LO, uint32_t &xspan)
+    {
+        // (every lane computes the span's few common values for itself: as wave-uniform values they would need some twenty scalar
+        // registers where none is free, and cost the kernel a vector register for their spills)
+        const uint32_t xav = 64u * (cav64 > 4096u ? 4096u : (uint32_t)cav64);
+        LaneVec<uint32_t> Q, QX, QT, Q63, J, A, B, Q8, WL;
+        LaneVec<bool> LE, BADP;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(Q, k) = strip_load(PROF_OFF + k);
+            PZG_LV(QX, k) = strip_load(PROF_OFF + 64u);
+            PZG_LV(QT, k) = strip_load(PROF_OFF + 65u);
+            PZG_LV(BADP, k) = strip_load(PROF_OFF + 66u) != PROF_MAGIC;
+            PZG_LV(J, k) = strip_load(PROF_OFF + 67u);  // streams for which the profile is not to be consulted (strip_profile_check)
+        PZG_LANES_END
+        if (lanes_ballot(BADP) != 0ull) {  // no profile yet (the scratch is as the allocator left it)
+            const uint32_t zero = prof_k(0u);  // (see prof_k: a pair of zeros in registers from the kernel's first line on, otherwise)
+            if (lane_id() == 0u || PZG_WAVE == 1u) {
+                strip[PROF_OFF + 67u] = zero;
+                strip[PROF_OFF + 68u] = zero;
+            }
+            return false;
+        }
+        PZG_LANES_BEGIN(k)
+            PZG_LV(BADP, k) = PZG_LV(J, k) != 0u;
+        PZG_LANES_END
+        if (lanes_ballot(BADP) != 0ull) {
+            const uint32_t left = lane_get(J, 0u) - 1u;
+            if (lane_id() == 0u || PZG_WAVE == 1u) strip[PROF_OFF + 67u] = left;
+            return false;
+        }
+        PZG_LANES_BEGIN(k)
+            PZG_LV(J, k) = 63u;
+        PZG_LANES_END
+        lanes_gather(Q63, Q, J);
+        PZG_LANES_BEGIN(k)
+            const uint32_t qt = PZG_LV(QT, k), qx = PZG_LV(QX, k);
+            PZG_LV(BADP, k) = (qt < 64u) | (qt > prof_k(64u * STRIP_TMAX)) | (qx > prof_k(1u << 18)) | (PZG_LV(Q63, k) >= qx) | ((k == 0u) & (PZG_LV(Q, k) != 0u));
+            PZG_LV(LE, k) = PZG_LV(Q, k) <= xav;
+        PZG_LANES_END
+        if (lanes_ballot(BADP) != 0ull) return false;
+        const uint32_t n = popc64(lanes_ballot(LE));  // quantiles at or below what the stream has left (1 or more: quantile 0 is bit 0)
+        PZG_LANES_BEGIN(k)
+            PZG_LV(J, k) = n - 1u;
+        PZG_LANES_END
+        lanes_gather(A, Q, J);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(J, k) = n;
+        PZG_LANES_END
+        lanes_gather(B, Q, J);
+        // the span's extent in quantiles (q8: 1/256ths): what the stream has left, or what PROF_TGT tokens per lane allow
+        PZG_LANES_BEGIN(k)
+            const uint32_t qx = PZG_LV(QX, k);
+            const uint32_t k8191 = prof_k(8191u), kmax = prof_k(448u << 8), k64 = prof_k(64u << 8), ktgt = prof_k(PROF_TGT << 20);
+            uint32_t wl = qx - PZG_LV(Q63, k);  // the last quantile's bits: what a quantile behind the profile's end is taken to be
+            wl = wl > k8191 ? k8191 : wl;
+            PZG_LV(WL, k) = wl;
+            const uint32_t a = PZG_LV(A, k), b = n < 64u ? PZG_LV(B, k) : qx;
+            const bool past = xav >= qx;
+            const uint32_t num = past ? xav - qx : xav - a, den = past ? wl : (b > a ? b - a : 1u);
+            uint32_t fr = prof_div(num << 8, den);
+            fr = fr > kmax ? kmax : fr;
+            uint32_t q8 = (past ? k64 : ((n - 1u) << 8)) + fr;
+            const uint32_t qcap = prof_div(ktgt, PZG_LV(QT, k));  // QT x q8 / (64 x 256) tokens over 64 lanes
+            PZG_LV(Q8, k) = q8 > qcap ? qcap : q8;
+        PZG_LANES_END
+        // lane k's strip begins at quantile k q / 64 (between two entries: in proportion); the span ends at quantile q
+        PZG_LANES_BEGIN(k)
+            const uint32_t i0 = (k * PZG_LV(Q8, k)) >> 14;
+            PZG_LV(J, k) = i0 < 63u ? i0 : 63u;
+        PZG_LANES_END
+        lanes_gather(A, Q, J);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(J, k) += 1u;
+        PZG_LANES_END
+        lanes_gather(B, Q, J);
+        PZG_LANES_BEGIN(k)
+            const uint32_t qx = PZG_LV(QX, k), wl = PZG_LV(WL, k);
+            const uint32_t x0 = (k * PZG_LV(Q8, k)) >> 6, i0 = x0 >> 8;
+            const uint32_t a0 = PZG_LV(A, k), a1 = i0 >= 63u ? qx : PZG_LV(B, k);
+            const uint32_t lo = i0 < 64u ? a0 + (((x0 & 255u) * (a1 - a0)) >> 8) : qx + (((x0 - prof_k(64u << 8)) * wl) >> 8);
+            PZG_LV(LO, k) = lo < xav ? lo : xav;
+        PZG_LANES_END
+        // (the end: what lane "64" would begin at)
+        PZG_LANES_BEGIN(k)
+            const uint32_t i1 = PZG_LV(Q8, k) >> 8;
+            PZG_LV(J, k) = i1 < 63u ? i1 : 63u;
+        PZG_LANES_END
+        lanes_gather(A, Q, J);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(J, k) += 1u;
+        PZG_LANES_END
+        lanes_gather(B, Q, J);
+        LaneVec<uint32_t> XE;
+        PZG_LANES_BEGIN(k)
+            const uint32_t qx = PZG_LV(QX, k), wl = PZG_LV(WL, k), q8 = PZG_LV(Q8, k), i1 = q8 >> 8;
+            const uint32_t e0 = PZG_LV(A, k), e1 = i1 >= 63u ? qx : PZG_LV(B, k);
+            const uint32_t xe = i1 < 64u ? e0 + (((q8 & 255u) * (e1 - e0)) >> 8) : qx + (((q8 - prof_k(64u << 8)) * wl) >> 8);
+            PZG_LV(XE, k) = xe < xav ? xe : xav;
+        PZG_LANES_END
+        const uint32_t xe = lane_get(XE, 0u);
+        if (xe < 64u * STRIP_CMIN) return false;
+        xspan = xe;
+        return true;
+    }
+    // The profile is only as good as the last stream resembles this one.  A batch of one kind is the rule -- but laid out by the
+    // profile of ANOTHER kind of stream, a span can be far worse than equal strips (measured on a batch that alternates text, html,
+    // literal-heavy and binary streams of five sizes: 17.8 ms with the profile trusted blindly, 11.6 ms without one): the strips of
+    // a text stream's decaying profile give the last lanes of a flat stream twice their share, or more tokens than a lane has steps.
+    // The run-ups know: each lane has just decoded the `back` bits in front of its strip and counted the tokens, so its strip of
+    // w bits will hold about cnt w / back of them.  If the mean of these estimates is more than a lane has steps for (this
+    // stream's tokens are shorter than the profile's), or one of them twice the mean, or the largest clearly more than the
+    // busiest of 64 EQUAL strips would get by the same counts, the span is laid out again in equal strips (a second phase A: ~5 %
+    // of the stream's time), and the profile is not consulted for the next few streams -- twice as many after every failure in a row.
+    PZG_FN bool strip_profile_check(const LaneVec<uint32_t> &CNT, const LaneVec<uint32_t> &LIM, uint32_t r0, uint32_t back, uint32_t xspan)
+    {
+        LaneVec<uint32_t> NEXT, LN, EST, ONE, E1, MX, SM, UX;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(NEXT, k) = k + 1u;
+            PZG_LV(ONE, k) = 1u;
+        PZG_LANES_END
+        lanes_gather(LN, LIM, NEXT);
+        PZG_LANES_BEGIN(k)
+            const uint32_t lim = PZG_LV(LIM, k), lo = lim - r0, w = (k == 63u ? r0 + xspan : PZG_LV(LN, k)) - lim;
+            const uint32_t rb = lo > back ? back : lo;  // the run-up's bits (none in lane 0, few in the lanes next to it)
+            PZG_LV(EST, k) = rb >= 64u ? prof_div(PZG_LV(CNT, k) * w, rb) : 0u;
+            PZG_LV(UX, k) = rb >= 64u ? prof_div(PZG_LV(CNT, k) * (xspan >> 6), rb) : 0u;  // ... and an equal strip around here
+        PZG_LANES_END
+        lanes_gather(E1, EST, ONE);  // (lanes without an estimate of their own: the first lane that has one is not far)
+        PZG_LANES_BEGIN(k)
+            PZG_LV(MX, k) = PZG_LV(EST, k);
+            PZG_LV(SM, k) = PZG_LV(EST, k) != 0u ? PZG_LV(EST, k) : PZG_LV(E1, k);
+        PZG_LANES_END
+        lanes_iscan_max(MX);
+        lanes_iscan_max(UX);
+        lanes_iscan_add(SM);
+        const uint32_t mx = lane_get(MX, 63u), sm = lane_get(SM, 63u), ux = lane_get(UX, 63u);
+#ifdef PZG_DBG_CHECK
+        fprintf(stderr, "check mx=%u mean=%.1f back=%u est:", mx, sm / 64.0, back);
+        for (uint32_t k = 0; k < 64u; ++k) fprintf(stderr, " %u", PZG_LV(EST, k));
+        fprintf(stderr, "\n");
+#endif
+        // (the estimates scatter by +-20 %: the mean says whether the lanes have steps enough, the largest whether one lane has far more than its share)
+        // and whether equal strips would not do better by the same estimates (the busiest of them: the span's extent / 64 at the densest run-up)
+        const bool ok = sm <= 64u * (STRIP_TMAX * 13u / 16u) && mx * 64u <= sm * 2u && mx * 8u <= ux * 9u;
+        if (lane_id() == 0u || PZG_WAVE == 1u) {
+            const uint32_t level = strip_load(PROF_OFF + 68u);
+            const uint32_t nl = ok ? 0u : (level >= 32u ? 64u : 2u * level + 2u);
+            strip[PROF_OFF + 68u] = nl;
+            strip[PROF_OFF + 67u] = nl;
+        }
+        return ok;
+    }
+    // ... and what the span that was just decoded teaches: lanes 0 .. last hold NR + NLB tokens each, from LO to HI (the last
+    // one to `xend`).  `ok`: every lane's start was verified and none ran out of steps -- anything else forgets the profile.
+    // (LIM - r0: where the strips end; a strip begins where the one in front of it ends)
+    PZG_FN void strip_profile_learn(const SeqOut &o, const LaneVec<uint32_t> &LIM, uint32_t r0, uint32_t last, uint32_t xend, bool ok)
+    {
+        LaneVec<uint32_t> TK, TI, CNT, HX, LO, PREV;
+        PZG_LANES_BEGIN(k)
+            PZG_LV(TK, k) = k <= last ? PZG_LV(o.NR, k) + PZG_LV(o.NLB, k) : 0u;
+            PZG_LV(TI, k) = PZG_LV(TK, k);
+            PZG_LV(HX, k) = k == last ? xend : PZG_LV(LIM, k) - r0;
+            PZG_LV(CNT, k) = 0u;
+            PZG_LV(PREV, k) = k - 1u;
+        PZG_LANES_END
+        lanes_gather(LO, HX, PREV);
+        PZG_LANES_BEGIN(k)
+            PZG_LV(LO, k) = k == 0u ? 0u : PZG_LV(LO, k);
+        PZG_LANES_END
+        lanes_iscan_add(TI);
+        const uint32_t T = lane_get(TI, 63u);
+        if (!ok || T < 64u || xend < 64u * STRIP_CMIN / 2u) {
+            const uint32_t zero = prof_k(0u);
+            if (!ok && (lane_id() == 0u || PZG_WAVE == 1u)) strip[PROF_OFF + 66u] = zero;
+            return;
+        }
+        // quantile j lies in the first strip i whose tokens, added up, exceed j/64 of all of them
+        for (uint32_t i = 0; i < 64u; ++i) {
+            const uint32_t ti64 = lane_get(TI, i) << 6;
+            PZG_LANES_BEGIN(j)
+                PZG_LV(CNT, j) += ti64 <= j * T ? 1u : 0u;
+            PZG_LANES_END
+        }
+        LaneVec<uint32_t> GT, GI, GL, GH;
+        lanes_gather(GT, TK, CNT);
+        lanes_gather(GI, TI, CNT);
+        lanes_gather(GL, LO, CNT);
+        lanes_gather(GH, HX, CNT);
+        PZG_LANES_BEGIN(j)
+            const uint32_t t = PZG_LV(GT, j), te = PZG_LV(GI, j) - t, lo = PZG_LV(GL, j), hi = PZG_LV(GH, j);
+            const uint32_t num = j * T - (te << 6);  // (below 64 t)
+            // (num / 64 t of the strip's bits: t <= STRIP_TMAX, the strip below 2^18 bits -- in 1/256ths of a token)
+            const uint32_t q = lo + ((prof_div(num << 2, t ? t : 1u) * (hi > lo ? hi - lo : 0u)) >> 8);
+            strip[PROF_OFF + j] = j == 0u ? 0u : q;
+        PZG_LANES_END
+        if (lane_id() == 0u || PZG_WAVE == 1u) {
+            strip[PROF_OFF + 64u] = xend;
+            strip[PROF_OFF + 65u] = T;
+            strip[PROF_OFF + 66u] = prof_k(PROF_MAGIC);
+        }
+    }
+
     // Decodes and emits one span.  STRIP_NA: nothing done (too little input ahead; the windows take over);
     // ST_OK: the span's tokens are all out, the cursor stands behind them -- at a stopper if `stopper`; else an error status.
     // `poor` is set when the span ended after few strips because the guesses kept failing.
     template <bool FX>
-    PZG_FN int strip_span(bool &stopper, bool &poor)
+    PZG_FN int strip_span(bool &stopper, bool &poor, bool &tight)
     {
         stopper = false;
         const int64_t av = br.avail();
         if (av < (int64_t)(64u * STRIP_CMIN + 192u)) return STRIP_NA;
-        // no strip holds more tokens than its bits / the block's shortest literal/length code
-        uint32_t minlen = 7u;
+        // A lane decodes at most STRIP_TMAX tokens (its region holds no more; phase B counts its steps).  No strip of STRIP_TMAX x the
+        // block's shortest literal/length code bits can hold more -- but that bound is far from what a strip does hold (text: codes
+        // from 4 bits, 6.7 bits per token), and a 32 KiB stream took two spans and two run-ups where one does.  So the strips are as
+        // long as the code's own expectation allows: a symbol of length l turns up with probability ~2^-l under the code the
+        // compressor built for it, which makes sum(count[l] l 2^-l) bits the mean literal/length code (a match's extra bits and
+        // distance only make tokens longer); 7/8 of STRIP_TMAX such tokens.  A lane that runs out of steps all the same ends the span
+        // where it stands (nothing is lost but the strips behind it), and the block's later spans keep to the hard bound (`tight`).
+        uint32_t minlen = 7u, mean15 = 8u << 15;  // (the fixed code: 7 / 8.03 bits)
         if (!FX) {
-            minlen = 1u;
-            while (minlen < 15u && uni(L.lit_meta.count[minlen]) == 0u) ++minlen;
+            minlen = 0u;
+            mean15 = 0u;
+            for (uint32_t l = 1u; l <= 15u; ++l) {
+                const uint32_t c = uni(L.lit_meta.count[l]);
+                if (minlen == 0u && c != 0u) minlen = l;
+                mean15 += (c * l) << (15u - l);
+            }
+            if (minlen == 0u) minlen = 15u;
+            if (mean15 > (15u << 15)) mean15 = 15u << 15;
         }
-        const uint64_t cav = ((uint64_t)av - 192u) >> 6;  // the last strip ends 192 bits or more in front of the stream's end
-        uint32_t C = cav > 4096u ? 4096u : (uint32_t)cav;
-        if (C > STRIP_TMAX * minlen) C = STRIP_TMAX * minlen;
+        const uint64_t cav64 = ((uint64_t)av - 192u) >> 6;  // the last strip ends 192 bits or more in front of the stream's end
+        uint32_t cmax = STRIP_TMAX * minlen;
+        if (!tight) {
+            const uint32_t est = ((STRIP_TMAX * 7u / 8u) * (mean15 >> 7)) >> 8;
+            if (est > cmax) cmax = est;
+        }
+        if (cmax > 4096u) cmax = 4096u;
+        // what is left of the stream goes into spans of equal strips (a last span of short strips pays the same run-up as a full one)
+        uint32_t C = cmax;
+        if (cav64 <= cmax) C = (uint32_t)cav64;
+        else if (cav64 < 8u * cmax) {
+            uint32_t nsp = 2u;
+            while (nsp * cmax < (uint32_t)cav64) ++nsp;
+            C = ((uint32_t)cav64 + nsp - 1u) / nsp;
+        }
         if (C < STRIP_CMIN) return STRIP_NA;
         while (qn != 0u) {  // (tokens a checked step queued: they go first)
             const int se = emit_segment();
@@ -2464,27 +2740,63 @@ struct Decoder {
         if (back < STRIP_BACK_MIN || back > STRIP_BACK) back = STRIP_BACK;
         StripReader rd;
         LaneVec<uint32_t> P, S, LIM;
-        PZG_LANES_BEGIN(k)
-            const uint32_t lo = k * C;
-            PZG_LV(LIM, k) = r0 + lo;
-            const uint32_t p = r0 + (lo > back ? lo - back : 0u);  // (from the cursor itself: exact)
-            PZG_LV(P, k) = p;
-            strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
-            PZG_SR(TA) = PZG_SR(TB) = 0ull;
-            PZG_SR(PA) = PZG_SR(PB) = 0u;
-        PZG_LANES_END
-        for (;;) {
-            if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TA, rd.PA)) break;
-            if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TB, rd.PB)) break;
+        // (short strips -- a 4 KiB stream's hold ~30 tokens -- differ by chance more than by position: no profile for them)
+        const bool head = STRIP_PROFILE && bit0 < PROF_HEAD && cav64 >= PROF_CMIN;
+        uint32_t xspan = 64u * C;  // where the last strip ends
+        for (bool by_profile = head && !tight;;) {
+            {
+                LaneVec<uint32_t> LO;
+                if (!(by_profile && strip_profile_layout(cav64, LO, xspan))) {
+                    by_profile = false;
+                    xspan = 64u * C;
+                    PZG_LANES_BEGIN(k)
+                        PZG_LV(LO, k) = k * C;
+                    PZG_LANES_END
+                }
+                PZG_LANES_BEGIN(k)
+                    PZG_LV(LIM, k) = r0 + PZG_LV(LO, k);
+                PZG_LANES_END
+            }
+            LaneVec<uint32_t> CNT;
+            PZG_LANES_BEGIN(k)
+                const uint32_t lo = PZG_LV(LIM, k) - r0;
+                const uint32_t p = r0 + (lo > back ? lo - back : 0u);  // (from the cursor itself: exact)
+                PZG_LV(P, k) = p;
+                PZG_LV(CNT, k) = 0u;
+                strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
+                PZG_SR(TA) = PZG_SR(TB) = 0ull;
+                PZG_SR(PA) = PZG_SR(PB) = 0u;
+            PZG_LANES_END
+            for (;;) {
+                if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TA, rd.PA, CNT)) break;
+                if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TB, rd.PB, CNT)) break;
+            }
+            strip_drain(rd);
+            // strips laid out by the profile: do the run-ups agree with it?  If not, once more with equal strips
+            if (!by_profile) break;
+            if (strip_profile_check(CNT, LIM, r0, back, xspan)) {
+                PZG_STAT(30, 1);  // spans laid out by the profile
+                break;
+            }
+            PZG_STAT(31, 1);  // layouts the run-ups rejected
+            by_profile = false;
         }
-        strip_drain(rd);
         // phase B: the strips, until every lane started where its neighbour ended
         PZG_HOT_ACC(8, tsa);
         PZG_T0(tsb);
         SeqOut o;
+        {   // a strip ends where the next one begins
+            LaneVec<uint32_t> NEXT, LN;
+            PZG_LANES_BEGIN(k)
+                PZG_LV(NEXT, k) = k + 1u;
+            PZG_LANES_END
+            lanes_gather(LN, LIM, NEXT);
+            PZG_LANES_BEGIN(k)
+                PZG_LV(LIM, k) = k == 63u ? r0 + xspan : PZG_LV(LN, k);
+            PZG_LANES_END
+        }
         PZG_LANES_BEGIN(k)
             PZG_LV(S, k) = PZG_LV(P, k);
-            PZG_LV(LIM, k) += C;
             PZG_LV(o.STF, k) = 0u;
             PZG_LV(o.OB, k) = 0u;
             PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
@@ -2510,13 +2822,17 @@ struct Decoder {
                     }
                 PZG_LANES_END
             }
-            for (;;) {
+            for (uint32_t steps = 0; steps < STRIP_TMAX; steps += 2u) {  // (a token a step at the most: the regions cannot overflow)
                 if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM, rd.TA, rd.PA)) break;
                 if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM, rd.TB, rd.PB)) break;
             }
             strip_drain(rd);
             PZG_LANES_BEGIN(k)
-                if (lane_bit(dirty, k)) strip_finish_lane(o, k);
+                if (lane_bit(dirty, k)) {
+                    // out of steps in front of the end of its strip: the span ends where the lane stands, as at a stopper
+                    if ((PZG_LV(o.STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k))) PZG_LV(o.STF, k) = 2u;
+                    strip_finish_lane(o, k);
+                }
             PZG_LANES_END
             // lane k must have started where lane k - 1's chain left its strip; lanes behind the first one that stopped do not count
             LaneVec<uint32_t> NS, PREV;
@@ -2570,8 +2886,12 @@ struct Decoder {
                 stopm = 0ull;
             }
         }
-        stopper = stopm != 0ull && lane_get(o.STF, last) == 1u;
+        const uint32_t stf_last = stopm != 0ull ? lane_get(o.STF, last) : 0u;
+        stopper = stf_last == 1u;
+        if (stf_last == 2u) tight = true;
+        PZG_STAT(29, stf_last == 2u ? 1 : 0);  // spans ended by a lane out of steps
         const uint32_t pend = lane_get(P, last);
+        if (head) strip_profile_learn(o, LIM, r0, last, pend - r0, dirty == 0ull && stf_last != 2u);
         PZG_HOT_ACC(9, tsb);
         PZG_T0(tsc);
         seq_index(o.NR, last);
@@ -3303,14 +3623,14 @@ struct Decoder {
     template <bool FX>
     PZG_FN int token_loop()
     {
-        bool strips = STRIPS && strip != nullptr;
+        bool strips = STRIPS && strip != nullptr, tight = false;
         for (;;) {
             PZG_T0(tw);
             bool checked;
             bool span_done = false;
             if (strips) {
                 bool poor = false;
-                const int ss = strip_span<FX>(checked, poor);
+                const int ss = strip_span<FX>(checked, poor, tight);
                 if (ss != ST_OK && ss != STRIP_NA) return ss;  // (an error first: a poor span can end in one too)
                 if (ss == STRIP_NA || poor) strips = false;
                 if (ss == ST_OK && !checked) continue;
@@ -3906,14 +4226,14 @@ struct Decoder {
     PZG_FN int token_loop_res()
     {
         if (deferred != 0u) susp_pos = stream_bit_pos();  // (resumed while draining: nothing of this call's input is consumed yet)
-        bool strips = STRIPS && strip != nullptr;
+        bool strips = STRIPS && strip != nullptr, tight = false;
         for (;;) {
             int st;
             bool span_stopper = false;
             if (deferred == 0u && strips) {
                 // (round 5) a span of strips while the call's input and room have space for one: decoded and emitted inside this call
                 bool poor = false;
-                const int ss = strip_span<false>(span_stopper, poor);
+                const int ss = strip_span<false>(span_stopper, poor, tight);
                 if (ss == ST_OUT_FULL) {
                     susp_pos = stream_bit_pos();
                     return ST_OUT_FULL;

@@ -9,204 +9,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "inflate_core.h"
-#include "pzg_launch.h"
+#include "pzg_inflate_kernel.h"
 
 namespace pzg {
-
-// ------------------------------------------------------------------------------------------------
-// inflate: a persistent grid of one-wave workgroups (block = 64 threads), each pulling stream indices
-// from a device counter.  LDS per workgroup = sizeof(WaveLds): 36 KiB at RING_BITS = 15 (four
-// stream-waves per CU, one per SIMD) down to 6 KiB at RING_BITS = 11 (26 per CU).
-// Waves per SIMD each instance is compiled for (its VGPR budget: 512 / waves, in steps of 8) and the
-// resident stream-waves per CU that follow from it and from sizeof(WaveLds) against the 160 KiB of LDS.
-#ifndef PZG_MIN_WAVES_11
-#define PZG_MIN_WAVES_11 7
-#endif
-// (the gzip instance of ring 11 needs more vector registers than the zlib one: 80, six waves per SIMD, 24 stream-waves per CU
-// instead of 26 -- round 5, once the prefetch pick-up's 4 * lane no longer lived in a register pair for the kernel's whole
-// life; rounds 3-4: 96 registers, five waves -- and nothing in scratch)
-#ifndef PZG_MIN_WAVES_11_GZIP
-#define PZG_MIN_WAVES_11_GZIP 6
-#endif
-constexpr int waves_per_simd(int ring_bits, bool gzip = false)
-{
-    return ring_bits <= 11 ? (gzip ? PZG_MIN_WAVES_11_GZIP : PZG_MIN_WAVES_11) : ring_bits == 12 ? 5 : ring_bits == 13 ? 4 : ring_bits == 14 ? 2 : 1;
-}
-template <int RING_BITS, bool GZIP = false>
-constexpr uint32_t waves_per_cu()
-{
-    constexpr uint32_t by_lds = (160u * 1024u) / (uint32_t)((sizeof(WaveLds<RING_BITS>) + 511u) / 512u * 512u);
-    constexpr uint32_t by_vgpr = 4u * (uint32_t)(RING_BITS >= 13 ? 4 : waves_per_simd(RING_BITS, GZIP));  // rings 13-15 fit 128 VGPRs
-    return by_lds < by_vgpr ? by_lds : by_vgpr;
-}
-
-// The launch arguments are NOT kept in scalar registers across a stream: the decoder's own wave-uniform state
-// already fills the scalar register file (what does not fit is spilled into vector-register lanes, and uniform
-// values start living in vector registers inside the hot loop).  They are read from the kernel-argument segment
-// when a stream starts and again when its results are stored; the empty asm makes the pointer opaque at those two
-// points so that the loads are not hoisted out of the stream loop.
-typedef const InflateArgs __attribute__((address_space(4))) *LaunchArgs;  // (constant address space: scalar loads)
-__device__ __forceinline__ LaunchArgs launch_args()
-{
-    LaunchArgs kp = (LaunchArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp)::"memory");
-    return kp;
-}
-
-template <int RING_BITS, bool FIXUP, bool GZIP = false>
-__global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_kernel(InflateArgs)
-{
-    __shared__ WaveLds<RING_BITS> lds;
-    if (FIXUP && __builtin_nontemporal_load(launch_args()->counter + 1) == 0u) return;  // nothing was handed back
-    if (threadIdx.x == 0) lds.fixed_ready = 0u;  // LDS is not zeroed at launch
-    __syncthreads();
-    // Persistent stream-waves: the grid is sized to the residency of the chip and every wave pulls
-    // stream indices from one device-scope counter until the batch is drained (a returning atomic is
-    // ~0.3-1 us, nothing next to a >= 50 us stream; launching one workgroup per stream instead costs
-    // more in dispatch than the small streams take to decode).
-    for (;;) {
-        uint32_t i = 0;
-        StreamResult r;
-        {
-            LaunchArgs a = launch_args();
-            if (threadIdx.x == 0) i = atomicAdd(a->counter, 1u);
-            i = uni(i);
-            if (i >= a->n) break;
-#if !defined(PZG_PROFILE)
-            if (a->order) i = a->order[i];
-#endif
-            // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
-            if (FIXUP && a->status[i] != ST_RETRY_FULL_RING) continue;
-            Decoder<RING_BITS, GZIP> dec(lds);
-            if (!FIXUP && a->strip && blockIdx.x < a->strip_waves) dec.strip = a->strip + (size_t)blockIdx.x * Decoder<RING_BITS, GZIP>::STRIP_WORDS;
-            const uint8_t *dict = nullptr;
-            uint32_t dict_len = 0;
-            if (!GZIP && a->dict_len) {  // extension (PZG_FDICT): this stream's preset dictionary, if it has one
-                const uint64_t dl = a->dict_len[i];
-                dict = a->dict_base + a->dict_off[i];
-                dict_len = dl > 0xffffffffull ? 0xffffffffu : (uint32_t)dl;
-            }
-            dec.run(a->in_base + a->in_off[i], a->in_len[i], a->out_base + a->out_off[i], a->out_cap[i], &r, dict, dict_len);
-#if defined(PZG_PROFILE)
-            // diagnostic build: the 16 phase counters of stream i go to prof_out[16*i ..]
-            if (threadIdx.x == 0 && a->prof_out)
-                for (int q = 0; q < 16; ++q) a->prof_out[16 * (size_t)i + q] = dec.prof[q];
-#endif
-        }
-        LaunchArgs a = launch_args();
-        if (threadIdx.x == 0) {
-            a->status[i] = r.status;
-            if (!FIXUP && r.status == ST_RETRY_FULL_RING) atomicAdd(a->counter + 1, 1u);
-            a->out_len[i] = r.out_len;
-            if (a->detail) {
-                a->detail[2 * (size_t)i] = r.detail0;
-                a->detail[2 * (size_t)i + 1] = r.detail1;
-            }
-            if (a->in_used) a->in_used[i] = r.in_used;
-            if (a->adler) a->adler[i] = GZIP ? 0u : r.adler;  // gzip: crc32_verify_kernel fills in the CRC-32
-            if (GZIP) {
-                a->gz_expect[2 * (size_t)i] = r.gz_crc;
-                a->gz_expect[2 * (size_t)i + 1] = (uint32_t)r.out_len;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The resumable decoder (decompressIncremental, Monad.hs:163-197): one launch continues a batch of suspended decoders,
-// one wave each, as far as their new input and output room go.  Round 4: the small-ring instance (PZG_RES_RING = 12: 8 KiB
-// of LDS, four waves per SIMD, 16 decoders per CU where the 32 KiB LDS ring allowed 4).  What is older than the ring comes
-// from the decoder's own 32 KiB history in HBM (every flush writes there as well as to the call's room), and a call saves /
-// restores 8 KiB of LDS image instead of 37.
-#ifndef PZG_RES_RING
-#define PZG_RES_RING 12
-#endif
-#ifndef PZG_RES_WAVES_PER_SIMD
-#define PZG_RES_WAVES_PER_SIMD 4
-#endif
-constexpr int RES_RING = PZG_RES_RING;
-__global__ __launch_bounds__(64, RES_RING == 15 ? 1 : PZG_RES_WAVES_PER_SIMD) void inflate_resume_kernel(ResumeArgs a)
-{
-    __shared__ WaveLds<RES_RING> lds;
-    for (;;) {
-        uint32_t i = 0;
-        if (threadIdx.x == 0) i = atomicAdd(a.counter, 1u);
-        i = uni(i);
-        if (i >= a.n) break;
-        uint8_t *slot = a.state_base + (size_t)i * a.state_stride;
-        ResumeState *rs = (ResumeState *)slot;
-        uint32_t *image = (uint32_t *)(slot + ResumeSlot<RES_RING>::IMAGE_OFF);
-        Decoder<RES_RING, false, true> dec(lds);
-        if (a.strip && blockIdx.x < a.strip_waves) dec.strip = a.strip + (size_t)blockIdx.x * Decoder<RES_RING, false, true>::STRIP_WORDS;
-        StreamResult r;
-        uint32_t chunks = 0;
-        dec.run_resume(rs, image, slot + ResumeSlot<RES_RING>::HIST_OFF, a.in_base + a.in_off[i], a.in_len[i], a.out_base + a.out_off[i],
-                       a.out_cap[i], a.final_in ? (uint32_t)a.final_in[i] : 0u, &r, &chunks);
-        if (threadIdx.x == 0) {
-            a.status[i] = r.status;
-            a.out_len[i] = r.out_len;
-            a.in_used[i] = r.in_used;
-            a.chunks[i] = chunks;
-            if (a.adler) a.adler[i] = r.adler;
-            if (a.detail) {
-                a.detail[2 * (size_t)i] = r.detail0;
-                a.detail[2 * (size_t)i + 1] = r.detail1;
-            }
-        }
-        if (a.dense) {
-            // what this decoder delivered, once more, behind what the others of its range delivered: the host then fetches ONE
-            // linear span per range instead of rooms that are mostly empty (the bytes are this wave's own stores of a moment
-            // ago: L2 hits; 64 lanes x 16 bytes per step, four steps in flight)
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const uint32_t nv = (uint32_t)((r.out_len + 15u) >> 4);
-            uint32_t at = 0;
-            if (threadIdx.x == 0) at = atomicAdd(a.dense_cursor, nv);
-            at = uni(at);
-            const uint64_t off = a.dense_region + 16ull * at;
-            if (threadIdx.x == 0) a.dense_off[i] = off;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the flushes' stores have landed
-            const u32x4 *src = (const u32x4 *)(const void *)(a.out_base + a.out_off[i]);
-            u32x4 *dst = (u32x4 *)(void *)(a.dense + off);
-            for (uint32_t v0 = 0; v0 < nv; v0 += 256u) {
-                u32x4 t[4];
-#pragma unroll
-                for (uint32_t q = 0; q < 4u; ++q) {
-                    const uint32_t v = v0 + 64u * q + threadIdx.x;
-                    t[q] = __builtin_nontemporal_load(src + (v < nv ? v : nv - 1u));
-                }
-#pragma unroll
-                for (uint32_t q = 0; q < 4u; ++q) {
-                    const uint32_t v = v0 + 64u * q + threadIdx.x;
-                    if (v < nv) dst[v] = t[q];
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-size_t resume_scalar_bytes() { return sizeof(ResumeState); }
-size_t resume_state_bytes() { return ResumeSlot<RES_RING>::BYTES; }
-
-size_t resume_strip_wave_bytes() { return (size_t)Decoder<RES_RING, false, true>::STRIP_WORDS * sizeof(uint32_t); }
-uint32_t resume_launch_waves(int num_cus, uint32_t n)
-{
-    constexpr uint32_t by_lds = (160u * 1024u) / (uint32_t)((sizeof(WaveLds<RES_RING>) + 511u) / 512u * 512u);
-    constexpr uint32_t by_vgpr = RES_RING == 15 ? 4u : 4u * PZG_RES_WAVES_PER_SIMD;
-    const uint32_t waves = (uint32_t)num_cus * (by_lds < by_vgpr ? by_lds : by_vgpr);
-    return waves > n ? n : waves;
-}
-
-hipError_t launch_resume(const ResumeArgs &a, int num_cus, hipStream_t stream)
-{
-    if (a.n == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(inflate_resume_kernel, dim3(resume_launch_waves(num_cus, a.n)), dim3(64), 0, stream, a);
-    return hipGetLastError();
-}
 
 // ------------------------------------------------------------------------------------------------
 // CRC-32 (RFC 1952 section 8) of each decoded gzip member against its trailer: an extension (the reference has
@@ -380,10 +185,11 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     // Ring size classes.  15: the whole 32 KiB DEFLATE window is an LDS ring (4 stream-waves per CU).
     // 12-14: a smaller near ring plus far back-references served from the stream's own flushed output
     // (more resident stream-waves per CU; the kernel is latency-bound, so that is what it scales with).
+    // (the gzip instances live in pzg_kernels_b.hip)
 #define PZG_LAUNCH_RING(RB)                                                                   \
     do {                                                                                      \
         if (a.gzip)                                                                           \
-            hipLaunchKernelGGL((inflate_kernel<RB, false, true>), grid, block, 0, stream, a); \
+            e = launch_inflate_gzip(a, RB, false, waves, stream);                             \
         else                                                                                  \
             hipLaunchKernelGGL((inflate_kernel<RB, false, false>), grid, block, 0, stream, a); \
     } while (0)
@@ -400,6 +206,7 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
     else
         return hipErrorInvalidValue;
 #undef PZG_LAUNCH_RING
+    if (e != hipSuccess) return e;
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ring_bits != 15) {
@@ -407,9 +214,10 @@ hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipS
         e = hipMemsetAsync(a.counter, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
         dim3 fgrid(a.n < 1024u ? a.n : 1024u);
-        if (a.gzip)
-            hipLaunchKernelGGL((inflate_kernel<15, true, true>), fgrid, block, 0, stream, a);
-        else
+        if (a.gzip) {
+            e = launch_inflate_gzip(a, 15, true, fgrid.x, stream);
+            if (e != hipSuccess) return e;
+        } else
             hipLaunchKernelGGL((inflate_kernel<15, true, false>), fgrid, block, 0, stream, a);
     }
     e = hipGetLastError();

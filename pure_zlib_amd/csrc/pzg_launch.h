@@ -72,6 +72,8 @@ uint32_t resume_launch_waves(int num_cus, uint32_t n);  // workgroups of a launc
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);
 size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip);  // what InflateArgs::strip holds when every stream-wave of that launch owns a slice
 size_t inflate_strip_wave_bytes();  // ... one stream-wave's slice
+// the gzip instances (pzg_kernels_b.hip): `waves` workgroups of the ring's kernel, or of the fixup pass
+hipError_t launch_inflate_gzip(const InflateArgs &a, int ring_bits, bool fixup, uint32_t waves, hipStream_t stream);
 
 // partials: 3 * 4 * ceil(max_waves / 4) uint32 of device scratch
 hipError_t launch_adler32(const uint8_t *buf, uint64_t len, uint32_t init, uint32_t *partials, uint32_t max_waves,

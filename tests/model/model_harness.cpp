@@ -38,11 +38,22 @@ static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t c
     pzg::Decoder<RB, GZ> dec(*lds);
     pzg::StreamResult sr;
     // the wave's token scratch (strips); PZM_NO_STRIPS=1 in the environment: the windows alone, as on a launch without scratch
-    uint32_t *strip = getenv("PZM_NO_STRIPS") ? nullptr : (uint32_t *)malloc(sizeof(uint32_t) * pzg::Decoder<RB, GZ>::STRIP_WORDS);
-    if (strip) memset(strip, 0xC3, sizeof(uint32_t) * pzg::Decoder<RB, GZ>::STRIP_WORDS);
+    // (it outlives the call, as a persistent wave's scratch outlives its streams: the wave's profile -- strip_profile_learn() -- is in it;
+    // PZM_FRESH_SCRATCH=1: a new one, filled with garbage, every call)
+    static uint32_t *kept = nullptr;
+    const bool fresh = getenv("PZM_FRESH_SCRATCH") != nullptr;
+    uint32_t *strip = nullptr;
+    if (!getenv("PZM_NO_STRIPS")) {
+        if (fresh || !kept) {
+            strip = (uint32_t *)malloc(sizeof(uint32_t) * pzg::Decoder<RB, GZ>::STRIP_WORDS);
+            memset(strip, 0xC3, sizeof(uint32_t) * pzg::Decoder<RB, GZ>::STRIP_WORDS);
+            if (!fresh) kept = strip;
+        } else
+            strip = kept;
+    }
     dec.strip = strip;
     dec.run(buf + 8, in_len, out, cap, &sr);
-    free(strip);
+    if (fresh) free(strip);
     r->status = sr.status;
     r->detail0 = sr.detail0;
     r->detail1 = sr.detail1;

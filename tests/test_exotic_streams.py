@@ -20,7 +20,7 @@ POOR_FLAGS = ["-DPZG_STRIP_BACK=8", "-DPZG_STRIP_ROUNDS=2"]  # the strips' run-u
 def lab_library(tag, flags):
     """build/lab_<tag>/libpzg.so: the product's sources with extra -D options (tests/tools/lab_build.sh), rebuilt when a source is newer."""
     so = os.path.join(ROOT, "build", "lab_" + tag, "libpzg.so")
-    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_kernels.hip", "pzg_launch.h", "pzg_helpers.h", "pzg_api.cpp",
+    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_inflate_kernel.h", "pzg_kernels.hip", "pzg_kernels_b.hip", "pzg_launch.h", "pzg_helpers.h", "pzg_api.cpp",
                                                                     "pzg_errors.cpp", "pzg.map")] + [os.path.join(ROOT, "include", "pzg.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call([os.path.join(ROOT, "tests", "tools", "lab_build.sh"), tag, *flags])

@@ -186,6 +186,42 @@ def test_exotic_streams_vs_oracle(ctx, oracle):
     _check_against_oracle(oracle, streams, caps, res, outs, datas)
 
 
+def test_strips_laid_out_by_a_profile_of_another_kind_of_stream(ctx, oracle):
+    """Round 5: a stream-wave remembers how the tokens of the last stream's first span were spread (strip_profile_learn) and cuts
+    the next stream's strips at those positions -- checked by the run-ups, laid out again in equal strips when they disagree
+    (strip_profile_check), forgotten when a lane runs out of steps.  Nothing about the result may depend on any of it: 1,280
+    streams whose neighbours differ in kind (text, html, literal-heavy, binary, writer-made), size (8-64 KiB), level and validity,
+    launched THREE times (every wave's profile after the first launch is whatever its last stream left there), every launch
+    against the oracle: status, message, in_used, Adler-32, every byte."""
+    import deflate_writer as W
+    rng = np.random.default_rng(11)
+    kinds = []
+    for i in range(40):
+        size = int(rng.choice([8192, 16384, 24576, 32768, 49152, 65536]))
+        d = [corpus.zipf_text, corpus.html_slice, corpus.skewed_bytes, corpus.mixed_data][i % 4](size, i)
+        kinds.append((d, zlib.compress(d, [6, 1, 9, 6, 3][(i // 4) % 5])))
+    for seed in (0, 3, 5, 7):
+        d, z, _ = W.exotic_stream(seed)
+        kinds.append((d, z))
+    streams, caps, datas = [], [], []
+    for j in rng.integers(0, len(kinds), 1280):
+        d, z = kinds[j]
+        bad = rng.integers(0, 8) == 0
+        streams.append(corpus.corrupt(z, int(rng.integers(0, 1 << 20))) if bad else z)
+        caps.append(len(d))
+        datas.append(None if bad else d)
+    expect = [oracle.decompress(z, c) for z, c in zip(streams, caps)]
+    for launch in range(3):
+        res, outs, _, _ = run_batch(ctx, streams, caps)
+        out_len, status, detail, in_used, adler = res
+        for k, (r, o) in enumerate(expect):
+            assert status[k] == r.status, (launch, k, status[k], r.status)
+            if r.status == 0:
+                assert outs[k] == o and int(adler[k]) == r.adler and int(in_used[k]) == r.in_used, (launch, k)
+                assert datas[k] is None or o == datas[k], (launch, k)
+    _check_against_oracle(oracle, streams[:200], caps[:200], (out_len[:200], status[:200], detail[:200], in_used[:200], adler[:200]), outs[:200], datas[:200])
+
+
 def test_strips_with_failing_guesses_on_the_device(tmp_path):
     """the "guesses keep failing" path of the strips (spans that end after a strip or two, `poor`, the rest
     of the block left to the windows; repaired lanes re-storing their regions) had only run on the one-lane host model, which

@@ -172,6 +172,40 @@ def test_model_strips_when_the_guesses_fail(model_bad_guesses, oracle, rb):
             assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
 
 
+@pytest.fixture(scope="session")
+def model_few_steps():
+    """The host model with 80 steps (and tokens) per lane and span: strips run out of steps, spans end at the lane that did
+    (strip_span(): STF 2, `tight`), and the wave's profile is forgotten and learnt again all the time."""
+    return _build_model(["-DPZG_STRIP_TMAX=80", "-DPZG_PROF_CMIN=256"])
+
+
+@pytest.mark.parametrize("which,rb", [("model", 11), ("model", 15), ("few", 11), ("few", 13)])
+def test_model_strips_laid_out_by_the_last_streams_profile(model, model_few_steps, oracle, which, rb):
+    """Round 5: a wave remembers where the tokens of the last stream's first span lay (strip_profile_learn: in its scratch, which
+    the model keeps from call to call as a persistent wave does) and cuts the next stream's strips there, unless the run-ups
+    disagree (strip_profile_check).  Nothing about the result may depend on it: 90 streams in a row whose neighbours differ in kind,
+    size, level and validity -- every one against the oracle; and the same with lanes that run out of steps all the time."""
+    import numpy as np
+    run = model if which == "model" else model_few_steps
+    rng = np.random.default_rng(5)
+    kinds = []
+    for i in range(16):
+        size = int(rng.choice([12288, 24576, 32768, 49152]))
+        d = [corpus.zipf_text, corpus.html_slice, corpus.skewed_bytes, corpus.mixed_data][i % 4](size, i)
+        kinds.append((d, zlib.compress(d, [6, 1, 9, 6, 3][(i // 4) % 5])))
+    seq = list(rng.integers(0, len(kinds), 60)) + [0] * 10 + [1, 2] * 10  # (a run of one kind: the profile settles; then two kinds in turn)
+    for n, j in enumerate(seq[: 90 if which == "model" else 50]):
+        d, z = kinds[j]
+        if n % 7 == 3:
+            zc = corpus.corrupt(z, n)
+            ro, oo = oracle.decompress(zc, len(d))
+            rm, om = run(zc, len(d), rb)
+            assert same(ro, oo, rm, om), (n, j, ro.status, rm.status, ro.message)
+        else:
+            r, out = run(z, len(d), rb)
+            assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), (n, j)
+
+
 @pytest.mark.parametrize("rb", [15, 14, 11])
 def test_model_gzip_members(model, oracle, rb):
     """The gzip extension (RFC 1952 header / CRC-32 + ISIZE trailer around the same DEFLATE core): the kernel

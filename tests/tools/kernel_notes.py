@@ -7,8 +7,15 @@ for lib in (sys.argv[1:] or [os.path.join(ROOT, "pure_zlib_amd", "libpzg.so")]):
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "co.elf")
         subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, lib, os.path.join(d, "unused.so")])
-        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
-        notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co]).decode()
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
+        notes = ""
+        for n, at in enumerate(starts):  # one bundle per translation unit that holds kernels
+            part = os.path.join(d, "fat%d.bin" % n)
+            open(part, "wb").write(blob[at:starts[n + 1] if n + 1 < len(starts) else len(blob)])
+            subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                   "--input=" + part, "--output=" + co])
+            notes += subprocess.check_output([llvm + "/llvm-readelf", "--notes", co]).decode()
     print(os.path.basename(lib))
     for block in notes.split("- .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", block).group(1)

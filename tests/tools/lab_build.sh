@@ -9,6 +9,7 @@ out=../../build/lab_$tag
 mkdir -p $out
 F="-O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-function -fno-unroll-loops"
 /opt/rocm/bin/hipcc $F -mllvm -structurizecfg-skip-uniform-regions=true -mllvm -align-all-nofallthru-blocks=5 "$@" -c pzg_kernels.hip -o $out/k.o
+/opt/rocm/bin/hipcc $F -mllvm -structurizecfg-skip-uniform-regions=true -mllvm -align-all-nofallthru-blocks=5 -mllvm -amdgpu-sdwa-peephole=0 "$@" -c pzg_kernels_b.hip -o $out/kb.o
 /opt/rocm/bin/hipcc $F "$@" -c pzg_api.cpp -o $out/api.o
 g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -c pzg_errors.cpp -o $out/errors.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared $out/k.o $out/api.o $out/errors.o -Wl,-rpath,/opt/rocm/lib -Wl,--version-script=pzg.map -o $out/libpzg.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared $out/k.o $out/kb.o $out/api.o $out/errors.o -Wl,-rpath,/opt/rocm/lib -Wl,--version-script=pzg.map -o $out/libpzg.so

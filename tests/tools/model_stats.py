@@ -15,7 +15,8 @@ NAMES = ["windows (hot loop)", "tokens queued by clean windows", "segments", "se
          "ended by a source inside the segment", "ended by the queue running out", "sum of qn at segment start", "bytes of segments",
          "tokens of segments", "segments with a second pass", "head token for copy_match / bail", "checked steps",
          "strip spans", "records of strip spans", "phase-B rounds", "phase-A steps", "phase-B steps", "spans cut at a wrong start", "lanes that counted",
-         "groups", "sequences of groups", "bytes of groups", "copy rounds", "solo sequences + long matches in groups", "groups with far matches", "dword steps", "byte steps", "sum of exact dependency depths"]
+         "groups", "sequences of groups", "bytes of groups", "copy rounds", "solo sequences + long matches in groups", "groups with far matches", "dword steps", "byte steps", "sum of exact dependency depths",
+         "spans ended by a lane out of steps", "spans laid out by the profile", "profile layouts the run-ups rejected"]
 
 
 def build():

@@ -7,7 +7,8 @@ cd "$(dirname "$0")/../../pure_zlib_amd/csrc"
 mkdir -p ../../build/noflags
 F="-O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-function -fno-unroll-loops"
 /opt/rocm/bin/hipcc $F -c pzg_kernels.hip -o ../../build/noflags/k.o
+/opt/rocm/bin/hipcc $F -c pzg_kernels_b.hip -o ../../build/noflags/kb.o
 # (its own API objects, always rebuilt: a stale build/pzg/pzg_api.o would test old host code)
 /opt/rocm/bin/hipcc $F -c pzg_api.cpp -o ../../build/noflags/api.o
 g++ -O2 -std=c++17 -fPIC -fvisibility=hidden -c pzg_errors.cpp -o ../../build/noflags/errors.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared ../../build/noflags/k.o ../../build/noflags/api.o ../../build/noflags/errors.o -Wl,-rpath,/opt/rocm/lib -Wl,--version-script=pzg.map -o ../../build/noflags/libpzg.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared ../../build/noflags/k.o ../../build/noflags/kb.o ../../build/noflags/api.o ../../build/noflags/errors.o -Wl,-rpath,/opt/rocm/lib -Wl,--version-script=pzg.map -o ../../build/noflags/libpzg.so

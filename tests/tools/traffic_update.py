@@ -18,7 +18,7 @@ def main():
     # (only the hash function is needed: read it without importing torch)
     import hashlib
     h = hashlib.sha256()
-    for fn in ("inflate_core.h", "pzg_kernels.hip", "wave.h"):
+    for fn in ("inflate_core.h", "pzg_inflate_kernel.h", "pzg_kernels.hip", "pzg_kernels_b.hip", "wave.h"):
         with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     sha = h.hexdigest()
