@@ -2070,7 +2070,7 @@ struct Decoder {
                             // 269 / 123 / 139; 192: 263 / 241 / 272 / 134 / 141; 224: 261 / 243 / 277 / 127 / 138; 256: 260 / 247 / 277 / 120 / 141)
 #endif
 #ifndef PZG_STRIP_BACK
-#define PZG_STRIP_BACK 768
+#define PZG_STRIP_BACK 1024  // (round 5, once a 32 KiB stream is ONE span: a repair re-decodes a strip twice as long as before -- 768: 300.4, 1024: 305.1 GiB/s)
 #endif
     static constexpr uint32_t STRIP_TMAX = PZG_STRIP_TMAX;      // tokens one lane may decode per span (a multiple of 16)
     // (a strip of C <= STRIP_TMAX x the shortest code bits holds at most STRIP_TMAX tokens, so at most as many records and literal
@@ -2098,6 +2098,11 @@ struct Decoder {
 #define PZG_STRIP_PROFILE 1
 #endif
     static constexpr bool STRIP_PROFILE = PZG_STRIP_PROFILE != 0 && !RES;
+    // (the profile's code runs once per stream: laid out as the unlikely side of its branches it stays out of the way of everything
+    // that runs per token -- see DESIGN.md 4.1 for what its mere presence cost the windows' loop before)
+#ifndef PZG_PROF_LIKELY
+#define PZG_PROF_LIKELY(x) __builtin_expect(!!(x), 0)
+#endif
     static constexpr uint32_t PROF_TGT = STRIP_TMAX * 3u / 4u;  // tokens per lane that a span laid out by the profile aims at
 #ifndef PZG_PROF_CMIN
 #define PZG_PROF_CMIN 512
@@ -2475,6 +2480,15 @@ struct Decoder {
 #endif
         return c;
     }
+    // ... and a lane number that is not worth one either: the address of "the profile's dword of this lane" is the same for the
+    // kernel's whole life, and would be computed in its first lines and kept (spilled) until the one place that uses it
+    PZG_FN static uint32_t prof_lane(uint32_t k)
+    {
+#if PZG_DEVICE_PASS
+        asm volatile("" : "+v"(k));
+#endif
+        return k;
+    }
     PZG_FN bool strip_profile_layout(uint64_t cav64, LaneVec<uint32_t> &LO, uint32_t &xspan)
     {
         // (every lane computes the span's few common values for itself: as wave-uniform values they would need some twenty scalar
@@ -2483,7 +2497,7 @@ struct Decoder {
         LaneVec<uint32_t> Q, QX, QT, Q63, J, A, B, Q8, WL;
         LaneVec<bool> LE, BADP;
         PZG_LANES_BEGIN(k)
-            PZG_LV(Q, k) = strip_load(PROF_OFF + k);
+            PZG_LV(Q, k) = strip_load(PROF_OFF + prof_lane(k));
             PZG_LV(QX, k) = strip_load(PROF_OFF + 64u);
             PZG_LV(QT, k) = strip_load(PROF_OFF + 65u);
             PZG_LV(BADP, k) = strip_load(PROF_OFF + 66u) != PROF_MAGIC;
@@ -2491,10 +2505,11 @@ struct Decoder {
         PZG_LANES_END
         if (lanes_ballot(BADP) != 0ull) {  // no profile yet (the scratch is as the allocator left it)
             const uint32_t zero = prof_k(0u);  // (see prof_k: a pair of zeros in registers from the kernel's first line on, otherwise)
-            if (lane_id() == 0u || PZG_WAVE == 1u) {
-                strip[PROF_OFF + 67u] = zero;
-                strip[PROF_OFF + 68u] = zero;
-            }
+            // (the profile's few common words are stored by every lane alike -- the same value to the same address -- never under a
+            // test of the lane number: ONE lane-dependent branch in this code made the compiler structurize the region around it, which
+            // reaches as far as the windows' loop: 23 % more vector and 26 % more scalar instructions for a 2 KiB stream, measured)
+            strip[PROF_OFF + 67u] = zero;
+            strip[PROF_OFF + 68u] = zero;
             return false;
         }
         PZG_LANES_BEGIN(k)
@@ -2502,7 +2517,7 @@ struct Decoder {
         PZG_LANES_END
         if (lanes_ballot(BADP) != 0ull) {
             const uint32_t left = lane_get(J, 0u) - 1u;
-            if (lane_id() == 0u || PZG_WAVE == 1u) strip[PROF_OFF + 67u] = left;
+            strip[PROF_OFF + 67u] = left;
             return false;
         }
         PZG_LANES_BEGIN(k)
@@ -2619,8 +2634,8 @@ struct Decoder {
         // (the estimates scatter by +-20 %: the mean says whether the lanes have steps enough, the largest whether one lane has far more than its share)
         // and whether equal strips would not do better by the same estimates (the busiest of them: the span's extent / 64 at the densest run-up)
         const bool ok = sm <= 64u * (STRIP_TMAX * 13u / 16u) && mx * 64u <= sm * 2u && mx * 8u <= ux * 9u;
-        if (lane_id() == 0u || PZG_WAVE == 1u) {
-            const uint32_t level = strip_load(PROF_OFF + 68u);
+        {   // (every lane alike: see strip_profile_layout)
+            const uint32_t level = uni(strip_load(PROF_OFF + 68u));
             const uint32_t nl = ok ? 0u : (level >= 32u ? 64u : 2u * level + 2u);
             strip[PROF_OFF + 68u] = nl;
             strip[PROF_OFF + 67u] = nl;
@@ -2648,7 +2663,7 @@ struct Decoder {
         const uint32_t T = lane_get(TI, 63u);
         if (!ok || T < 64u || xend < 64u * STRIP_CMIN / 2u) {
             const uint32_t zero = prof_k(0u);
-            if (!ok && (lane_id() == 0u || PZG_WAVE == 1u)) strip[PROF_OFF + 66u] = zero;
+            if (!ok) strip[PROF_OFF + 66u] = zero;  // (`ok` is the same in every lane)
             return;
         }
         // quantile j lies in the first strip i whose tokens, added up, exceed j/64 of all of them
@@ -2668,13 +2683,11 @@ struct Decoder {
             const uint32_t num = j * T - (te << 6);  // (below 64 t)
             // (num / 64 t of the strip's bits: t <= STRIP_TMAX, the strip below 2^18 bits -- in 1/256ths of a token)
             const uint32_t q = lo + ((prof_div(num << 2, t ? t : 1u) * (hi > lo ? hi - lo : 0u)) >> 8);
-            strip[PROF_OFF + j] = j == 0u ? 0u : q;
+            strip[PROF_OFF + prof_lane(j)] = j == 0u ? 0u : q;
         PZG_LANES_END
-        if (lane_id() == 0u || PZG_WAVE == 1u) {
-            strip[PROF_OFF + 64u] = xend;
-            strip[PROF_OFF + 65u] = T;
-            strip[PROF_OFF + 66u] = prof_k(PROF_MAGIC);
-        }
+        strip[PROF_OFF + 64u] = xend;
+        strip[PROF_OFF + 65u] = T;
+        strip[PROF_OFF + 66u] = prof_k(PROF_MAGIC);
     }
 
     // Decodes and emits one span.  STRIP_NA: nothing done (too little input ahead; the windows take over);
@@ -2741,12 +2754,13 @@ struct Decoder {
         StripReader rd;
         LaneVec<uint32_t> P, S, LIM;
         // (short strips -- a 4 KiB stream's hold ~30 tokens -- differ by chance more than by position: no profile for them)
-        const bool head = STRIP_PROFILE && bit0 < PROF_HEAD && cav64 >= PROF_CMIN;
+        // (... and none for blocks of the fixed code: level-1 output of a few KiB is what they are in practice)
+        const bool head = STRIP_PROFILE && !FX && bit0 < PROF_HEAD && cav64 >= PROF_CMIN;
         uint32_t xspan = 64u * C;  // where the last strip ends
         for (bool by_profile = head && !tight;;) {
             {
                 LaneVec<uint32_t> LO;
-                if (!(by_profile && strip_profile_layout(cav64, LO, xspan))) {
+                if (!(PZG_PROF_LIKELY(by_profile) && strip_profile_layout(cav64, LO, xspan))) {
                     by_profile = false;
                     xspan = 64u * C;
                     PZG_LANES_BEGIN(k)
@@ -2773,7 +2787,7 @@ struct Decoder {
             }
             strip_drain(rd);
             // strips laid out by the profile: do the run-ups agree with it?  If not, once more with equal strips
-            if (!by_profile) break;
+            if (!PZG_PROF_LIKELY(by_profile)) break;
             if (strip_profile_check(CNT, LIM, r0, back, xspan)) {
                 PZG_STAT(30, 1);  // spans laid out by the profile
                 break;
@@ -2891,7 +2905,7 @@ struct Decoder {
         if (stf_last == 2u) tight = true;
         PZG_STAT(29, stf_last == 2u ? 1 : 0);  // spans ended by a lane out of steps
         const uint32_t pend = lane_get(P, last);
-        if (head) strip_profile_learn(o, LIM, r0, last, pend - r0, dirty == 0ull && stf_last != 2u);
+        if (PZG_PROF_LIKELY(head)) strip_profile_learn(o, LIM, r0, last, pend - r0, dirty == 0ull && stf_last != 2u);
         PZG_HOT_ACC(9, tsb);
         PZG_T0(tsc);
         seq_index(o.NR, last);

@@ -74,8 +74,8 @@ def test_ring11_kernels_use_no_scratch():
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
     for name, k in ring11.items():
         # (round 4: strip_span() keeps ~30 more wave-uniform values alive beside the decoder's state -- 128 -> 256; round 5: the
-        # groups' masks are scalar pairs -- 288; the strips' profile -- 320)
-        assert k["sgpr_spill_count"] <= 320, (name, k["sgpr_spill_count"])
+        # groups' masks are scalar pairs -- 288; the strips' profile, written without a lane-dependent branch -- 336)
+        assert k["sgpr_spill_count"] <= 336, (name, k["sgpr_spill_count"])
         assert k["vgpr_count"] <= 72, (name, k["vgpr_count"])  # zlib and (round 5, without the SDWA peephole) gzip: 7 waves per SIMD by registers
         assert k["group_segment_fixed_size"] <= 6144, name  # 26 stream-waves per CU
     # round 5: the resumable decoder's kernel keeps everything in registers too (pzg_kernels_b.hip: compiled without the SDWA
