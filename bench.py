@@ -373,9 +373,10 @@ def main():
                 **({"container": "gzip members (extension): CRC-32 + ISIZE verified by a second kernel"} if args.gzip else {}),
                 "window": "32 KiB LDS ring" if ring_bits == 15 else f"{2**ring_bits // 1024} KiB LDS near ring + far back-references from the stream's flushed output (HBM/L2)",
                 "decode": "strips: 64 lanes decode 64 consecutive pieces of a stream's input token by token (speculative starts, verified) and write "
-                          "them as sequences (literal run + match: a record and the literal bytes) to a per-wave scratch in HBM (64.5 KiB per resident "
+                          "them as sequences (literal run + match: a record and the literal bytes) to a per-wave scratch in HBM (64.8 KiB per resident "
                           "stream-wave, allocated by the library); then one lane copies one whole sequence inside the LDS ring, up to 64 sequences a "
-                          "group; 128-bit windows for stream tails and short streams",
+                          "group; a stream's first span is cut into strips of equal WORK by the wave's profile of the stream before it (checked by "
+                          "the run-ups); 128-bit windows for stream tails and short streams",
                 "verified": ("every stream: status, length, in_used, Adler-32 and full byte compare, on one more step run after the "
                              "timed region over POISONED output / status arrays") if bit_exact is not None else "skipped",
             },

@@ -132,8 +132,8 @@ typedef struct pzg_ctx pzg_ctx;
 
 /* Create a context on HIP device `device` (0-based).  One HIP stream + grow-only device
  * arenas for the host-pointer path.  Returns PZG_RC_NO_DEVICE when HIP has no usable device.
- * Device memory the library takes for itself, grow-only until pzg_shutdown: the kernels' scratch -- 64.5 KiB per stream-wave
- * of a launch (one wave per stream, at most the residency of the chip: 6,656 waves = 419 MiB on an MI355X), two such arenas per
+ * Device memory the library takes for itself, grow-only until pzg_shutdown: the kernels' scratch -- 64.8 KiB per stream-wave
+ * of a launch (one wave per stream, at most the residency of the chip: 6,656 waves = 421 MiB on an MI355X), two such arenas per
  * device for PZG_DEVICE_PTRS launches and one per host-path pipeline in use (four at the most: 2.5 GiB per device in the worst
  * case; PZG_OPT_SCRATCH_BYTES bounds it) -- beside the host path's staging arenas.  A launch whose scratch cannot be allocated,
  * or only in part, still decodes: the stream-waves without a slice take the slower path that needs none. */
@@ -174,11 +174,11 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
  *   (default: the machine's hardware threads, at most 24).  Set it while no host-pointer call is running. */
 #define PZG_OPT_HOST_THREADS 2
 /* PZG_OPT_SCRATCH_BYTES: upper bound, per device, on the scratch memory the LIBRARY allocates for its inflate kernels (0, the
- *   default: no bound).  A launch's stream-waves decode long runs of input through a scratch of 64.5 KiB each -- 419 MiB for a
+ *   default: no bound).  A launch's stream-waves decode long runs of input through a scratch of 64.8 KiB each -- 421 MiB for a
  *   launch that fills an MI355X (6,656 stream-waves) -- and a context keeps up to six such arenas per device, grow-only: two for
  *   device-pointer launches (overlapping launches must not share one) and one per host-path pipeline (four), 2.5 GiB at the
- *   most; a pzg_decoder object keeps one more for its feeds (at most 4,096 stream-waves: 258 MiB).  With a bound every arena gets an even share (bound / 6): only as many stream-waves as fit own a slice, the others
- *   decode by the slower path that needs no scratch; below 64.5 KiB per arena all of them do.  Results never depend on it.
+ *   most; a pzg_decoder object keeps one more for its feeds (at most 4,096 stream-waves: 259 MiB).  With a bound every arena gets an even share (bound / 6): only as many stream-waves as fit own a slice, the others
+ *   decode by the slower path that needs no scratch; below 64.8 KiB per arena all of them do.  Results never depend on it.
  *   Takes effect launch by launch (an arena larger than its share is released when it is next used). */
 #define PZG_OPT_SCRATCH_BYTES 3
 PZG_API int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
