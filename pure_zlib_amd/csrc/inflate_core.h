@@ -2253,22 +2253,23 @@ struct Decoder {
 #endif
         t.d = is_sub ? d2 : t.d;
     }
-    // A lane's reader: b0..b5 = the six dwords from dword 2 * g of the span on, r = the lane's position relative to b0's
-    // bit 0 (below 64 between steps), nx = the next pair of dwords to fetch.  A token is at most 48 bits: r + 48 <= 112, so b0..b3
-    // hold it; b4, b5 are the fetch in flight.  (Pairs past `maxdw` -- the stream's last dwords -- repeat that pair: no token
-    // of a span reaches there.)
-    // (round 4, measured: written as an ordinary load inside a lane-dependent branch, the fetch goes to a temporary register
-    // that is copied into place at once -- a wait for HBM in every step.  So the fetch is straight-line code: every step
-    // every lane loads a pair -- the lanes that move on their next one, the others the span's first, one cache line for all --
-    // into a landing register of the STEP (TA in even steps, TB in odd ones), and the pair is put in its place two steps
-    // later, at the top of the step that reuses the landing register: by then it has arrived.  A lane's two pairs in flight go
-    // to two slots, pair j to slot j & 1, and a shift takes the older one -- asked for at the lane's last shift but one, two
-    // steps ago or earlier, so it is always in its slot when it is wanted.)
+    // A lane's reader: W0, W1 = the pairs of dwords (64 bits each) that hold the lane's position, r = that position relative to W0's bit 0
+    // (below 64 when a token is decoded: a token is at most 48 bits, r + 48 <= 112, so W0 and W1 hold it), T = the pair behind W1, nx = T's
+    // dword index, TN = the pair that is landing.  (Pairs past `maxdw` -- the stream's last dwords -- repeat that pair: no token of a span
+    // reaches there.)  At the top of a step a lane that has moved past W0 takes W1 for W0 and T for W1 and asks for the pair behind
+    // them, which becomes T at the top of the next step; the fetch is straight-line code (round 4, measured: written as a load inside a
+    // lane-dependent branch it goes to a temporary that is copied into place at once -- a wait for HBM in every step): every lane loads
+    // every step, the lanes that did not move the span's first pair.
+    // Rounds 4-5 kept two pairs in flight in two slots, with two landing registers that alternated between the steps, so that a pair was
+    // asked for two steps before its use: 16 registers and 24 instructions a step.  Measured at the end of round 5: the second step of
+    // distance buys nothing (this reader: text 307.3, the same with two alternating landing registers and a lane that waits a step out
+    // when it moves twice in a row: 305.2; config 3 158.5 / 154.6) -- 11 registers, 13 instructions: config 3 148 -> 158 GiB/s, the rest
+    // +0.5 %.  What does NOT work is every lane asking for its own pair again every step (10 instructions): 64 lines through the first
+    // cache per step, text 304 -> 182.
     struct StripReader {
-        LaneVec<uint64_t> W0, W1, L0, L1;  // dwords (b0, b1), (b2, b3); the slots of the next two pairs
-        LaneVec<uint64_t> TA, TB;           // the landing registers
-        LaneVec<uint32_t> PA, PB;           // ... 0: nothing for this lane, 1 / 2: for slot 0 / 1
+        LaneVec<uint64_t> W0, W1, T, TN;  // ... TN: the pair that is landing; it becomes T at the top of the next step if PEND says so
         LaneVec<uint32_t> R, NX;
+        LaneVec<bool> PEND;
     };
     PZG_FN static uint64_t strip_pair(const uint32_t *sp, uint32_t i)
     {
@@ -2276,37 +2277,29 @@ struct Decoder {
         return (uint64_t)q[0] | ((uint64_t)q[1] << 32);
     }
     // position a lane's reader at bit p of the span
-    PZG_FN static void strip_open(const uint32_t *sp, uint32_t maxdw, uint32_t p, uint64_t &w0, uint64_t &w1, uint64_t &l0, uint64_t &l1,
-                                  uint32_t &r, uint32_t &nx)
+    PZG_FN static void strip_open(const uint32_t *sp, uint32_t maxdw, uint32_t p, uint64_t &w0, uint64_t &w1, uint64_t &t, uint32_t &r, uint32_t &nx, bool &pend)
     {
+        pend = false;
         const uint32_t g2 = (p >> 6) << 1;
         w0 = strip_pair(sp, g2 < maxdw ? g2 : maxdw);
         w1 = strip_pair(sp, g2 + 2u < maxdw ? g2 + 2u : maxdw);
-        const uint64_t a = strip_pair(sp, g2 + 4u < maxdw ? g2 + 4u : maxdw), b = strip_pair(sp, g2 + 6u < maxdw ? g2 + 6u : maxdw);
-        const bool odd = (g2 & 2u) != 0u;  // (pair j = dwords 2j, 2j + 1 belongs in slot j & 1)
-        l0 = odd ? b : a;
-        l1 = odd ? a : b;
+        t = strip_pair(sp, g2 + 4u < maxdw ? g2 + 4u : maxdw);
         r = p & 63u;
-        nx = g2 + 8u;
+        nx = g2 + 4u;
     }
-    // the pair that landed goes to its slot
-    PZG_FN static void strip_merge(uint64_t t, uint32_t pend, uint64_t &l0, uint64_t &l1)
+    // the top of a step: 64 bits on if the position says so, and the pair behind W1 asked for (again)
+    PZG_FN static void strip_top(const uint32_t *sp, uint32_t maxdw, uint64_t &w0, uint64_t &w1, uint64_t &t, uint64_t &tn, uint32_t &r, uint32_t &nx, bool &pend)
     {
-        l0 = pend == 1u ? t : l0;
-        l1 = pend == 2u ? t : l1;
-    }
-    // after a token: 64 bits on if the position says so -- the pairs move down, the next one is asked for
-    PZG_FN static void strip_advance(const uint32_t *sp, uint32_t maxdw, uint64_t &w0, uint64_t &w1, const uint64_t &l0, const uint64_t &l1,
-                                     uint32_t &r, uint32_t &nx, uint64_t &t, uint32_t &pend)
-    {
-        const bool sh = r >= 64u, odd = (nx & 2u) != 0u;
-        const uint64_t older = odd ? l1 : l0;
+        t = pend ? tn : t;
+        const bool sh = r >= 64u;
         w0 = sh ? w1 : w0;
-        w1 = sh ? older : w1;
-        t = strip_pair(sp, sh ? (nx < maxdw ? nx : maxdw) : 0u);
-        pend = sh ? (odd ? 2u : 1u) : 0u;
+        w1 = sh ? t : w1;
+        r &= 63u;
         nx += sh ? 2u : 0u;
-        r -= sh ? 64u : 0u;
+        // (the lanes that did not move ask for the span's first pair: one cache line for all of them -- asking for their own pair
+        // again costs the first cache 64 lines a step and the kernel 40 %, measured)
+        tn = strip_pair(sp, sh ? (nx < maxdw ? nx : maxdw) : 0u);
+        pend = sh;
     }
 #define PZG_SR(f) PZG_LV(rd.f, k)
     // one lane's token at its position: tb = its bits (>= 128: a stopper), tk = the token
@@ -2325,7 +2318,7 @@ struct Decoder {
     // One step of phase A for every lane still in its run-up; false: none is.  (T, PD: this step's landing register.)
     template <bool FX>
     PZG_FN bool strip_step_a(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, StripReader &rd, LaneVec<uint32_t> &P,
-                             const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD, LaneVec<uint32_t> &CNT)
+                             const LaneVec<uint32_t> &LIM, LaneVec<uint32_t> &CNT)
     {
         LaneVec<bool> ACT;
         PZG_LANES_BEGIN(k)
@@ -2334,14 +2327,13 @@ struct Decoder {
         if (lanes_ballot(ACT) == 0ull) return false;
         PZG_MARK("sa.begin");
         PZG_LANES_BEGIN(k)
-            strip_merge(PZG_LV(T, k), PZG_LV(PD, k), PZG_SR(L0), PZG_SR(L1));
+            strip_top(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(T), PZG_SR(TN), PZG_SR(R), PZG_SR(NX), PZG_SR(PEND));
             uint32_t tb, tk;
             strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk);
             const uint32_t adv = PZG_LV(ACT, k) ? (tb < 128u ? tb : 1u) : 0u;  // (no token here: this is not the chain yet)
             PZG_LV(CNT, k) += PZG_LV(ACT, k) ? 1u : 0u;  // (the run-up's tokens: strip_profile_check)
             PZG_LV(P, k) += adv;
             PZG_SR(R) += adv;
-            strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
         PZG_LANES_END
         PZG_MARK("sa.end");
         PZG_STAT(16, 1);  // steps of phase A
@@ -2370,7 +2362,7 @@ struct Decoder {
     // ... of phase B, for the lanes of `dirty` that have not reached the end of their strip
     template <bool FX>
     PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd, SeqOut &o,
-                             LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM, LaneVec<uint64_t> &T, LaneVec<uint32_t> &PD)
+                             LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM)
     {
         LaneVec<bool> ACT;
         PZG_LANES_BEGIN(k)
@@ -2379,7 +2371,7 @@ struct Decoder {
         if (lanes_ballot(ACT) == 0ull) return false;
         PZG_MARK("sb.begin");
         PZG_LANES_BEGIN(k)
-            strip_merge(PZG_LV(T, k), PZG_LV(PD, k), PZG_SR(L0), PZG_SR(L1));
+            strip_top(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(T), PZG_SR(TN), PZG_SR(R), PZG_SR(NX), PZG_SR(PEND));
             uint32_t tb, tk;
             strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk);
             const bool act = PZG_LV(ACT, k), stop = tb >= 128u;
@@ -2414,7 +2406,6 @@ struct Decoder {
             // lines, and the fewer and larger the pieces the less of it is written twice.)
             if (is_l & ((nlb & 15u) == 0u)) seq_store_lits(o, k, reg_lit(k) + nlb - 16u);
             if (emit & ((nr & (SEQ_G - 1u)) == 0u)) seq_store_records(o, k, reg_rec(k) + nr - SEQ_G);
-            strip_advance(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX), PZG_LV(T, k), PZG_LV(PD, k));
         PZG_LANES_END
         PZG_MARK("sb.end");
         PZG_STAT(17, 1);  // steps of phase B
@@ -2440,16 +2431,6 @@ struct Decoder {
         PZG_LV(o.LA[3], k) = funnel(0u, PZG_LV(o.LA[3], k), sh);
         seq_store_lits(o, k, reg_lit(k) + ((nlb + 3u) & ~3u) - 16u);
     }
-    PZG_FN void strip_drain(StripReader &rd)  // what is still landing goes to its slot
-    {
-        PZG_LANES_BEGIN(k)
-            strip_merge(PZG_SR(TA), PZG_SR(PA), PZG_SR(L0), PZG_SR(L1));
-            strip_merge(PZG_SR(TB), PZG_SR(PB), PZG_SR(L0), PZG_SR(L1));
-            PZG_SR(PA) = 0u;
-            PZG_SR(PB) = 0u;
-        PZG_LANES_END
-    }
-
     // ---- the wave's profile: strips of equal WORK ---------------------------------------------------------------------------
     // Phase B takes as many steps as the strip with the most tokens has tokens, and equal strips are far from equal work: a
     // stream's first tokens are literals (there is nothing to match yet) and its matches grow as the window fills -- measured on
@@ -2777,15 +2758,10 @@ struct Decoder {
                 const uint32_t p = r0 + (lo > back ? lo - back : 0u);  // (from the cursor itself: exact)
                 PZG_LV(P, k) = p;
                 PZG_LV(CNT, k) = 0u;
-                strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
-                PZG_SR(TA) = PZG_SR(TB) = 0ull;
-                PZG_SR(PA) = PZG_SR(PB) = 0u;
+                strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(T), PZG_SR(R), PZG_SR(NX), PZG_SR(PEND));
             PZG_LANES_END
-            for (;;) {
-                if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TA, rd.PA, CNT)) break;
-                if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, rd.TB, rd.PB, CNT)) break;
-            }
-            strip_drain(rd);
+            for (;;)
+                if (!strip_step_a<FX>(sp, maxdw, lsub, dsub, rd, P, LIM, CNT)) break;
             // strips laid out by the profile: do the run-ups agree with it?  If not, once more with equal strips
             if (!PZG_PROF_LIKELY(by_profile)) break;
             if (strip_profile_check(CNT, LIM, r0, back, xspan)) {
@@ -2832,15 +2808,12 @@ struct Decoder {
                         PZG_LV(o.STF, k) = 0u;
                         PZG_LV(o.OB, k) = 0u;
                         PZG_LV(o.NR, k) = PZG_LV(o.NLB, k) = PZG_LV(o.LR, k) = 0u;
-                        strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(L0), PZG_SR(L1), PZG_SR(R), PZG_SR(NX));
+                        strip_open(sp, maxdw, p, PZG_SR(W0), PZG_SR(W1), PZG_SR(T), PZG_SR(R), PZG_SR(NX), PZG_SR(PEND));
                     }
                 PZG_LANES_END
             }
-            for (uint32_t steps = 0; steps < STRIP_TMAX; steps += 2u) {  // (a token a step at the most: the regions cannot overflow)
-                if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM, rd.TA, rd.PA)) break;
-                if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM, rd.TB, rd.PB)) break;
-            }
-            strip_drain(rd);
+            for (uint32_t steps = 0; steps < STRIP_TMAX; ++steps)  // (a token a step at the most: the regions cannot overflow)
+                if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM)) break;
             PZG_LANES_BEGIN(k)
                 if (lane_bit(dirty, k)) {
                     // out of steps in front of the end of its strip: the span ends where the lane stands, as at a stopper
