@@ -50,7 +50,7 @@ extern "C" {
 #endif
 
 #define PZG_VERSION_MAJOR 0
-#define PZG_VERSION_MINOR 4
+#define PZG_VERSION_MINOR 5
 
 /* ---- call-level return codes (the int every function returns) ---------------- */
 #define PZG_RC_OK            0
@@ -181,6 +181,12 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
  *   decode by the slower path that needs no scratch; below 64.8 KiB per arena all of them do.  Results never depend on it.
  *   Takes effect launch by launch (an arena larger than its share is released when it is next used). */
 #define PZG_OPT_SCRATCH_BYTES 3
+/* PZG_OPT_BUNDLES (0.5): 1 (default) -- a PZG_DEVICE_PTRS launch of 32,768 or more zlib streams first takes its streams of the
+ *   FIXED code (what `compressobj(1, ..., Z_FIXED)` and level-1 encoders make of short records) 64 to a wavefront, one lane per
+ *   stream; every other stream, and every stream that is not plain (another block type, any error, a stream or capacity of a MiB or
+ *   more), is decoded by the ordinary one-stream-per-wavefront kernel as before.  2 -- launches of any size.  0 -- off.  Results never
+ *   depend on it; it needs no scratch memory. */
+#define PZG_OPT_BUNDLES 4
 PZG_API int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
 /* The only environment variable the library reads is PZG_RING_BITS (11..15): the default of PZG_OPT_RING_BITS for
  * contexts created afterwards. */

@@ -41,6 +41,7 @@ HOST_PINNED = 16  # host-pointer batches in page-locked arenas (pzg_host_alloc),
 OPT_RING_BITS = 1
 OPT_HOST_THREADS = 2
 OPT_SCRATCH_BYTES = 3
+OPT_BUNDLES = 4
 DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares

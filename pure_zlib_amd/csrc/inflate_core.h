@@ -121,7 +121,8 @@ enum : int32_t {
     ST_DICT = 20,         // extension (PZG_FDICT): detail0 = DICTID of the stream, detail1 = Adler-32 of the dictionary supplied
     ST_NEED_INPUT = 101,  // resumable decoder: every complete token of the input so far has been decoded; more input is needed
     ST_OUT_FULL = 102,    // resumable decoder: the output room of this call is used up; call again with what is left of the input
-    ST_RETRY_FULL_RING = 100  // internal: a small-ring launch met an output larger than its capacity; the 32 KiB ring kernel redoes the stream
+    ST_RETRY_FULL_RING = 100,  // internal: a small-ring launch met an output larger than its capacity; the 32 KiB ring kernel redoes the stream
+    ST_BUNDLE_TODO = 103      // internal (bundles, bundle_core.h): the stream is the ordinary kernel's
 };
 
 enum { TREE_CODELEN = 0, TREE_LITLEN = 1, TREE_DIST = 2 };

@@ -142,6 +142,7 @@ struct pzg_ctx {
     void *prof_buf = nullptr;  // diagnostic builds only
     std::unique_ptr<Helpers> helpers;
     std::atomic<uint64_t> scratch_cap{0};  // PZG_OPT_SCRATCH_BYTES: the kernels' scratch per device, at most (0: no limit)
+    std::atomic<int> bundles{1};           // PZG_OPT_BUNDLES
 };
 
 namespace {
@@ -217,6 +218,11 @@ void strip_for_launch(pzg_ctx *ctx, Arena &a, int num_cus, uint32_t n, uint32_t 
     args.strip = (uint32_t *)a.p;
     args.strip_waves = (uint32_t)(want / per_wave);
 }
+
+// Bundles (pzg_bundle_kernel.h) pay when the batch has more bundles than the chip has SIMDs to run them on: a lane decodes its
+// stream token by token, so a bundle takes as long as its longest stream whether 64 lanes are busy or one -- measured on 4 KiB
+// streams: ~0.9 ms a bundle against ~0.16 ms a stream for a stream-wave of the ordinary kernel, 6,656 of which run side by side.
+constexpr uint32_t BUNDLE_MIN_STREAMS = 32768u;
 
 void pinned_release(Pinned &a)
 {
@@ -411,6 +417,7 @@ int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
 #if defined(PZG_LAB)  // lab builds only: the windows alone
     if (getenv("PZG_NO_STRIPS")) a.strip = nullptr;
 #endif
+    a.bundle = (ctx->bundles.load() == 2 || (ctx->bundles.load() == 1 && a.n >= BUNDLE_MIN_STREAMS)) && !(flags & PZG_GZIP) && !a.dict_len ? 1u : 0u;
     HIP_TRY(ctx, hipEventRecord(sh.ev0, sh.stream));
     HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, sh.stream));
     HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
@@ -1037,6 +1044,10 @@ int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
     }
     if (option == PZG_OPT_SCRATCH_BYTES && value >= 0) {  // (takes effect launch by launch: an arena larger than its share is given back when next used)
         ctx->scratch_cap.store((uint64_t)value);
+        return PZG_RC_OK;
+    }
+    if (option == PZG_OPT_BUNDLES && value >= 0 && value <= 2) {
+        ctx->bundles.store((int)value);
         return PZG_RC_OK;
     }
     if (option == PZG_OPT_HOST_THREADS && value >= 1 && value <= 256) {  // (not while host-pointer calls are running)

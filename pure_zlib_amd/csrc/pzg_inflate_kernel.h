@@ -55,6 +55,8 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_k
 {
     __shared__ WaveLds<RING_BITS> lds;
     if (FIXUP && __builtin_nontemporal_load(launch_args()->counter + 1) == 0u) return;  // nothing was handed back
+    // (bundles, pzg_bundle_kernel.h: the launch's small streams of the fixed code are done; word 3 counts what was left to this kernel)
+    if (!FIXUP && !GZIP && launch_args()->bundle != 0u && __builtin_nontemporal_load(launch_args()->counter + 3) == 0u) return;
     if (threadIdx.x == 0) lds.fixed_ready = 0u;  // LDS is not zeroed at launch
     __syncthreads();
     // Persistent stream-waves: the grid is sized to the residency of the chip and every wave pulls
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_k
 #endif
             // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
             if (FIXUP && a->status[i] != ST_RETRY_FULL_RING) continue;
+            if (!FIXUP && !GZIP && a->bundle != 0u && a->status[i] != ST_BUNDLE_TODO) continue;  // a bundle's stream: done
             Decoder<RING_BITS, GZIP> dec(lds);
             if (!FIXUP && a->strip && blockIdx.x < a->strip_waves) dec.strip = a->strip + (size_t)blockIdx.x * Decoder<RING_BITS, GZIP>::STRIP_WORDS;
             const uint8_t *dict = nullptr;

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "pzg_inflate_kernel.h"
+#include "pzg_bundle_kernel.h"
 
 namespace pzg {
 
@@ -175,11 +176,18 @@ size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip
 }
 size_t inflate_strip_wave_bytes() { return (size_t)Decoder<11>::STRIP_WORDS * sizeof(uint32_t); }
 
-hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream)
+hipError_t launch_inflate(const InflateArgs &a_in, int ring_bits, int num_cus, hipStream_t stream)
 {
-    if (a.n == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back
+    if (a_in.n == 0) return hipSuccess;
+    InflateArgs a = a_in;
+    if (a.gzip || a.dict_len) a.bundle = 0u;
+    hipError_t e = hipMemsetAsync(a.counter, 0, 8 * sizeof(uint32_t), stream);  // [0] stream index, [1] streams handed back, [3] the bundles' (pzg_bundle_kernel.h)
     if (e != hipSuccess) return e;
+    if (a.bundle) {  // the small streams of the fixed code first, 64 of the launch order to a wave
+        hipLaunchKernelGGL(bundle_kernel, dim3((a.n + 63u) / 64u), dim3(64), 0, stream, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     const uint32_t waves = launch_waves(ring_bits, num_cus, a.n, a.gzip);
     dim3 grid(waves), block(64);
     // Ring size classes.  15: the whole 32 KiB DEFLATE window is an LDS ring (4 stream-waves per CU).

@@ -31,6 +31,9 @@ struct InflateArgs {
     // kernels then decode by windows alone.  Must not be shared with a launch that may run at the same time.
     uint32_t *strip;
     uint32_t strip_waves;     // stream-waves (workgroups 0 .. strip_waves - 1) that own a slice of it; the others decode by windows alone
+    // bundles (round 6; pzg_bundle_kernel.h): nonzero -- the launch's small streams of the fixed code are decoded 64 to a wave, one
+    // lane per stream, before the ordinary kernel takes what is left.  zlib streams without dictionaries only.
+    uint32_t bundle;
 };
 
 // one batched call of the resumable decoder (decompressIncremental): decoder i continues from its ResumeState

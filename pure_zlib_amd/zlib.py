@@ -201,6 +201,11 @@ class Context:
         """Upper bound, per device, on the scratch the library allocates for its inflate kernels (PZG_OPT_SCRATCH_BYTES; 0: no bound)."""
         _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_SCRATCH_BYTES, int(nbytes)), self._h)
 
+    def set_bundles(self, mode: int):
+        """PZG_OPT_BUNDLES: device-pointer launches take their streams of the fixed code 64 to a wavefront, one lane per stream
+        (0: never, 1: launches of 32,768 streams or more -- the default, 2: always).  Results are identical."""
+        _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_BUNDLES, int(mode)), self._h)
+
     def sync(self):
         _ffi.check(self._L.pzg_sync(self._h), self._h)
 

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "../../pure_zlib_amd/csrc/inflate_core.h"
+#include "../../pure_zlib_amd/csrc/bundle_core.h"
 
 struct pzm_result {
     int32_t status;
@@ -172,6 +173,53 @@ int pzm_decompress_dict(const uint8_t *in, uint64_t in_len, const uint8_t *dict,
     r->out_len = sr.out_len;
     r->in_used = sr.in_used;
     free(buf);
+    free(lds);
+    return 0;
+}
+
+// The bundles (bundle_core.h): up to 64 streams, lane k decodes stream k; what a lane does not take comes back with status
+// ST_BUNDLE_TODO (103: the ordinary kernel's).
+int pzm_bundle(const uint8_t *const *ins, const uint64_t *in_lens, uint8_t *const *outs, const uint64_t *caps, uint32_t n, pzm_result *r)
+{
+    if (n > 64u) return -1;
+    typedef pzg::Bundle B;
+    auto *lds = (pzg::BundleLds *)aligned_alloc(16, sizeof(pzg::BundleLds));
+    memset(lds, 0xA5, sizeof(*lds));
+    uint8_t *bufs[64] = {};
+    static uint32_t common[4] = {0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu, 0xEEEEEEEEu};
+    static uint8_t nowhere[16];
+    B::In bi;
+    B::Out bo;
+    for (uint32_t k = 0; k < 64u; ++k) {
+        const bool have = k < n;
+        const uint64_t len = have ? in_lens[k] : 0, cap = have ? caps[k] : 0;
+        if (have) {
+            bufs[k] = (uint8_t *)malloc(len + 16 + (k & 3u));
+            memset(bufs[k], 0xEE, len + 16 + (k & 3u));
+            if (len) memcpy(bufs[k] + 8 + (k & 3u), ins[k], len);  // (every alignment of a stream's first byte)
+        }
+        const bool on = have && len >= 8u && len < B::MAX_BYTES && cap < B::MAX_BYTES;
+        bi.IN.v[k] = have ? bufs[k] + 8 + (k & 3u) : (const uint8_t *)common;
+        bi.OUT.v[k] = have ? outs[k] : nowhere;
+        bi.LEN.v[k] = on ? (uint32_t)len : 0u;
+        bi.CAP.v[k] = on ? (uint32_t)cap : 0u;
+        bi.ON.v[k] = on ? 1u : 0u;
+    }
+    B::run(*lds, bi, common, bo);
+    for (uint32_t k = 0; k < n; ++k) {
+        memset(&r[k], 0, sizeof(r[k]));
+        if (bo.STATE.v[k] != B::BS_CLEAN) {
+            r[k].status = pzg::ST_BUNDLE_TODO;
+            continue;
+        }
+        r[k].status = (int32_t)bo.STATUS.v[k];
+        r[k].detail0 = bo.D0.v[k];
+        r[k].detail1 = bo.D1.v[k];
+        r[k].adler = bo.ADLER.v[k];
+        r[k].out_len = bo.OLEN.v[k];
+        r[k].in_used = bo.USED.v[k];
+    }
+    for (uint32_t k = 0; k < n; ++k) free(bufs[k]);
     free(lds);
     return 0;
 }

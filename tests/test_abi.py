@@ -86,7 +86,7 @@ def test_ring11_kernels_use_no_scratch():
 
 def test_version_and_strerror():
     L = _ffi.lib()
-    assert L.pzg_version() == 4  # (major << 16) | minor: 0.4 (round 4: PZG_HOST_PINNED + pzg_host_alloc, pzg_init_devices, PZG_OPT_HOST_THREADS)
+    assert L.pzg_version() == 5  # (major << 16) | minor: 0.5 (round 5: PZG_OPT_SCRATCH_BYTES; round 6: PZG_OPT_BUNDLES)
     assert b"no CPU fallback" in L.pzg_strerror(_ffi.RC_NO_DEVICE)
 
 
