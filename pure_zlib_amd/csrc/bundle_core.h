@@ -12,8 +12,8 @@
 //     (dword d of lane k at win[(d & 127) * 64 + k]: every lane has a bank of its own, whatever its position) -- the window is
 //     the lane's alone, so it is written by whole dwords (the partial last dword rides in a register and is rewritten every step);
 //   * a token becomes a chunk of 1..8 bytes appended per step: a literal, 8 bytes of a near match (read as three aligned dwords
-//     and funnel-shifted), or 8 bytes of a FAR match -- older than the window: read from the stream's own flushed output, the
-//     load landing in a register that comes round again FAR_LAND steps later while the lane waits and the others go on;
+//     and funnel-shifted), or 8 bytes of a FAR match -- older than the window: read from the stream's own flushed output by a
+//     load that is asked for in the step's first lines and used in its last;
 //     a match longer than 8 bytes (or one that overlaps itself: the distance doubles as the pattern repeats) takes more steps;
 //   * every PHASE steps the wave flushes the lanes' completed 16-byte groups to their outputs, folds them into the lanes'
 //     Adler-32 (Adler32.hs:17-57), refills the input rings if a lane is down to half of its own, and finishes the lanes whose
@@ -46,11 +46,6 @@ struct Bundle {
     static constexpr uint32_t BQ_PAIRS = BundleLds::BQ_PAIRS, WIN_DW = BundleLds::WIN_DW, WIN_BYTES = 4u * WIN_DW;
     static constexpr uint32_t NEAR_MAX = WIN_BYTES - 16u; // a distance up to this is read from the window (the append may clobber the 12 oldest bytes)
     static constexpr uint32_t PHASE = 4u;                 // steps between two looks at the rings and the flushes
-#ifndef PZG_BUNDLE_FAR_LAND
-#define PZG_BUNDLE_FAR_LAND 1
-#endif
-    static constexpr uint32_t FAR_LAND = PZG_BUNDLE_FAR_LAND;  // steps a far load has to land
-    static_assert(PHASE % FAR_LAND == 0u, "the landing registers rotate with the unrolled steps");
     static constexpr uint32_t TK_MATCH = ENT_MATCH;
 
     struct In {                            // lane k's stream (ON = 0: none)
@@ -113,13 +108,12 @@ struct Bundle {
 
     struct State {
         LaneVec<const uint32_t *> SP;
-        LaneVec<uint64_t> W0, W1, NXT, FARV[FAR_LAND];
+        LaneVec<uint64_t> W0, W1, NXT, FARV[2];   // FARV: the far loads' landing registers (they alternate with the steps)
         LaneVec<uint32_t> MAXDW, R, NX, RD, WR;       // the reader
         LaneVec<uint32_t> P, END, ST, BF;             // bit position, end of the input, BS_*, the block is the last one
         LaneVec<uint32_t> OB, FL, ACC;                // bytes produced, bytes flushed (a multiple of 16), the partial last dword
         LaneVec<uint32_t> ML, MD;                     // the match under way: bytes still to copy, its (effective) distance
-        LaneVec<uint32_t> FN[FAR_LAND];               // bytes the far load of this slot brings (0: none on its way)
-        LaneVec<uint32_t> FW;                         // a far load of this lane is on its way
+        LaneVec<uint32_t> FN[2];                      // bytes the far load of this slot brings (0: none on its way)
         LaneVec<uint32_t> AA, AB;                     // Adler-32 of the flushed bytes
         LaneVec<uint32_t> ENDP;                       // (BS_FIN) where the trailer starts, in bits
     };
@@ -156,15 +150,12 @@ struct Bundle {
             PZG_LV(s.P, k) = 8u * mis + 19u;
             PZG_LV(s.R, k) = 8u * mis + 19u;
             PZG_LV(s.OB, k) = PZG_LV(s.FL, k) = PZG_LV(s.ACC, k) = 0u;
-            PZG_LV(s.ML, k) = PZG_LV(s.MD, k) = PZG_LV(s.FW, k) = 0u;
+            PZG_LV(s.ML, k) = PZG_LV(s.MD, k) = 0u;
+            PZG_LV(s.FARV[0], k) = PZG_LV(s.FARV[1], k) = 0ull;
+            PZG_LV(s.FN[0], k) = PZG_LV(s.FN[1], k) = 0u;
             PZG_LV(s.AA, k) = 1u;
             PZG_LV(s.AB, k) = 0u;
             PZG_LV(s.ENDP, k) = 0u;
-#pragma unroll
-            for (uint32_t u = 0; u < FAR_LAND; ++u) {
-                PZG_LV(s.FARV[u], k) = 0ull;
-                PZG_LV(s.FN[u], k) = 0u;
-            }
             PZG_LV(bo.STATE, k) = BS_TODO;
             PZG_LV(bo.STATUS, k) = PZG_LV(bo.D0, k) = PZG_LV(bo.D1, k) = PZG_LV(bo.ADLER, k) = PZG_LV(bo.OLEN, k) = PZG_LV(bo.USED, k) = 0u;
         PZG_LANES_END
@@ -180,23 +171,23 @@ struct Bundle {
                 if (lanes_ballot(LIVE) == 0ull) break;
 #if PZG_DEVICE_PASS
                 // every store of the phases before this one has landed from here on: a far load of the steps that follow reads bytes
-                // that were flushed two phases ago or earlier (a far source ends 496 bytes or more behind the lane's position, a lane
+                // that were flushed two phases ago or earlier (a far source ends 488 bytes or more behind the lane's position, a lane
                 // produces at most 8 * PHASE bytes between two flushes)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                 if (lanes_ballot(LOW) != 0ull) {
                     PZG_LANES_BEGIN(k)
                         refill(PZG_LV(s.SP, k), PZG_LV(s.MAXDW, k), L.bq, k, PZG_LV(s.NX, k), PZG_LV(s.RD, k), PZG_LV(s.WR, k));
+                        // (a lane that moved on four times in the last phase -- 49 bits a step is the most a step consumes -- took its NXT
+                        // from a slot that had not been written yet: it is read again, now that the slot is)
+                        PZG_LV(s.NXT, k) = L.bq[(PZG_LV(s.RD, k) & (BQ_PAIRS - 1u)) * 64u + k];
                     PZG_LANES_END
                 }
                 flush_groups(L, bi, s);
                 finish_lanes(L, bi, s, bo);
             }
 #pragma unroll
-            for (uint32_t u0 = 0; u0 < PHASE; ++u0) {
-                const uint32_t u = u0 % FAR_LAND;
-                step(L, bi, common, s, u);
-            }
+            for (uint32_t u0 = 0; u0 < PHASE; ++u0) step(L, bi, common, s, u0 & 1u);  // (unrolled: the landing registers alternate)
         }
     }
 
@@ -275,8 +266,17 @@ struct Bundle {
         PZG_LANES_END
     }
 
-    // One step: every lane that runs appends one chunk -- a literal, up to eight bytes of the match under way, or what a far
-    // load brought -- or decodes the end of a block.  u: the landing register of this step.
+    // One step.  A lane with a match under way copies up to eight bytes of it (or asks for them, or takes what a far load
+    // brought); a lane without one decodes up to three literals -- three tokens in four of config 3's streams are literals; a
+    // literal of the fixed code is 8 or 9 bits, so the tokens behind the first are looked up at all the places they can start, in
+    // the same trip to the LDS as the first -- and the match behind them, whose first bytes go out in the same step as the
+    // literals: a chunk is 1..8 bytes (measured on config 3's streams: 1,183 steps for the longest of 64 where one token a step
+    // takes 2,504 and two literals or one match 1,609).  The distance code of the fixed code is five bits in reverse:
+    // arithmetic, no table -- a step is two trips to the LDS, the tables and then the window.  A match older than the window (FAR: nearly
+    // half of config 3's) is read from the stream's own flushed output, eight bytes a step: a step asks for the bytes that the NEXT step
+    // appends -- into one of two landing registers that alternate with the steps (u: this step's; the wave is alone on its SIMD, so a
+    // load that is used in the step that asks for it is waited for in full: measured).
+    PZG_FN static bool is_lit(uint32_t e) { return (e & (ENT_MATCH | ENT_STOP)) == 0u; }
     PZG_FN static void step(BundleLds &L, const In &bi, const uint32_t *common, State &s, uint32_t u)
     {
         LaneVec<uint32_t> TKS, WLO;
@@ -292,84 +292,103 @@ struct Bundle {
                 PZG_LV(s.R, k) &= 63u;
                 PZG_LV(s.NXT, k) = L.bq[(PZG_LV(s.RD, k) & (BQ_PAIRS - 1u)) * 64u + k];
             }
-            // ---- the token at the lane's position (Monad.hs:295-302 nextCode, Deflate.hs:106-120)
-            uint32_t tb, tk, wlo, e8, e9;
+            const uint32_t ob = PZG_LV(s.OB, k);
+            const uint32_t ml0 = PZG_LV(s.ML, k), md0 = PZG_LV(s.MD, k);
+            const bool run = PZG_LV(s.ST, k) == (uint32_t)BS_RUN;
+            const uint32_t fnc = PZG_LV(s.FN[u ^ 1u], k);  // bytes of a far match that the step before this one asked for: they go in now
+            // ---- every LDS read of the step: the tokens' entries, the window at the armed match's source
+            uint32_t wlo, whi;
             {
                 const uint64_t w0 = PZG_LV(s.W0, k), w1 = PZG_LV(s.W1, k);
                 const uint32_t b0 = (uint32_t)w0, b1 = (uint32_t)(w0 >> 32), b2 = (uint32_t)w1, b3 = (uint32_t)(w1 >> 32), r = PZG_LV(s.R, k);
                 const bool up = r >= 32u;
                 const uint32_t lo = up ? b1 : b0, mid = up ? b2 : b1, hi = up ? b3 : b2;
                 wlo = funnel(mid, lo, r);
-                const uint32_t whi = funnel(hi, mid, r);
-                const uint32_t e = L.lit[wlo & 511u];
-                // (a literal of the fixed code is 8 or 9 bits: the token BEHIND it is looked up at both places in the same trip)
-                e8 = L.lit[(wlo >> 8) & 511u];
-                e9 = L.lit[(wlo >> 9) & 511u];
-                const uint32_t w2 = funnel(whi, wlo, e);  // bits after the length code and its extra bits: the entry's [4:0], <= 14
-                const uint32_t d = L.dist[w2 & 31u];
-                const uint32_t en = e >> 8, dn = d >> 8;
-                const uint32_t xl = ubfe(wlo, en, e - en), xd = ubfe(w2, dn, d - dn);
-                const uint32_t m = (uint32_t)((int32_t)e >> 31);
-                const uint32_t tk_match = hi_halves(e, d) + shl16_add(xl, xd);
-                tb = byte0_sum(e, d & m);
-                tk = bit_select(m, tk_match, e);
+                whi = funnel(hi, mid, r);
             }
-            const uint32_t ob = PZG_LV(s.OB, k);
-            const uint32_t ml0 = PZG_LV(s.ML, k), fw = PZG_LV(s.FW, k), fn = PZG_LV(s.FN[u], k);
-            const bool run = PZG_LV(s.ST, k) == (uint32_t)BS_RUN;
-            const bool dec = run & (ml0 == 0u) & (fw == 0u);  // a lane decodes when no match is under way
-            const bool stop = tb >= 128u, tok = dec & !stop;
-            const bool m0 = (int32_t)tk < 0;
-            const uint32_t tlen = (tk >> 16) & 511u, tdist = tk & 0xffffu;
-            // what leaves the stream to the ordinary kernel: a token that reaches past the input's end, output past the capacity, a
-            // distance that reaches in front of the output
-            const bool bad = tok & ((PZG_LV(s.P, k) + tb > PZG_LV(s.END, k)) | (ob + tlen > PZG_LV(bi.CAP, k)) | (m0 & (tdist > ob)));
-            const bool ok = tok & !bad;
+            const uint32_t e1 = L.lit[wlo & 511u];
+            const uint32_t e8 = L.lit[(wlo >> 8) & 511u], e9 = L.lit[(wlo >> 9) & 511u];
+            const uint32_t e16 = L.lit[(wlo >> 16) & 511u], e17 = L.lit[(wlo >> 17) & 511u], e18 = L.lit[(wlo >> 18) & 511u];
+            const bool dec = run & (ml0 == 0u);
+            // ---- the tokens (Monad.hs:295-302 nextCode, Deflate.hs:106-120): literals 1..3, then the token to arm
+            const bool l1 = is_lit(e1);
+            const uint32_t n1 = e1 & 31u, e2 = (n1 & 1u) ? e9 : e8;
+            const bool l2 = l1 & is_lit(e2);
+            const uint32_t n12 = n1 + (e2 & 31u), e3 = n12 == 16u ? e16 : n12 == 17u ? e17 : e18;
+            const bool l3 = l2 & is_lit(e3);
+            const uint32_t n123 = n12 + (e3 & 31u);
+            const uint32_t pos = PZG_LV(s.P, k), end = PZG_LV(s.END, k), cap = PZG_LV(bi.CAP, k);
+            // (a literal is taken if it lies inside the input and the capacity; one that does not is the next step's first token)
+            const bool t1 = dec & l1 & (pos + n1 <= end) & (ob + 1u <= cap);
+            const bool t2 = t1 & l2 & (pos + n12 <= end) & (ob + 2u <= cap);
+            const bool t3 = t2 & l3 & (pos + n123 <= end) & (ob + 3u <= cap);
+            const uint32_t nl = t3 ? 3u : t2 ? 2u : t1 ? 1u : 0u;
+            // the token behind the literals that were taken (behind all three: none)
+            const uint32_t ea = !l1 ? e1 : !l2 ? e2 : e3, pa = !l1 ? 0u : !l2 ? n1 : n12;
+            const bool first = !l1;                                  // the token to arm is the step's first
+            const bool reach = first | (!l2 ? t1 : !l3 ? t2 : false);  // every literal in front of it was taken
+            const bool am = (int32_t)ea < 0;                         // a length: a match
+            const uint32_t wa = funnel(whi, wlo, pa);                // 32 bits from its first (pa <= 18; length + distance are 31 bits at the most)
+            const uint32_t na = (ea >> 8) & 31u, ta = ea & 31u;
+            const uint32_t mlen = ((ea >> 16) & 511u) + ubfe(wa, na, ta - na);
+            const uint32_t wd = wa >> ta;
+            const uint32_t dsym = bitrev32(wd) >> 27;                // the fixed distance code: five bits, first bit first (Deflate.hs:249-251)
+            const uint32_t de = dsym >= 4u ? (dsym >> 1) - 1u : 0u;
+            const uint32_t dbase = dsym >= 4u ? 1u + ((2u + (dsym & 1u)) << de) : 1u + dsym;  // Deflate.hs:203-237 distanceArray
+            const uint32_t mdist = dbase + ubfe(wd, 5u, de);
+            const uint32_t tba = ta + 5u + de;
+            const uint32_t bits_l = t3 ? n123 : t2 ? n12 : t1 ? n1 : 0u;
+            // what sends the stream to the ordinary kernel, when it is the step's FIRST token: a token that reaches past the input's
+            // end, output past the capacity, a distance in front of the output, a symbol that is none (behind literals it is left
+            // where it is and becomes a step's first token)
+            const bool mfit = (pos + pa + tba <= end) & (ob + nl + mlen <= cap) & (mdist <= ob + nl) & (dsym < 30u);
+            const bool arm = dec & reach & am & mfit;
+            const bool stop1 = dec & first & ((e1 & ENT_STOP) != 0u);
+            const bool bad = dec & ((first & am & !mfit) | (l1 & !t1));
             PZG_LV(s.ST, k) = bad ? (uint32_t)BS_TODO : PZG_LV(s.ST, k);
-            PZG_LV(STOPF, k) = dec & stop;
-            PZG_LV(TKS, k) = tk;
+            PZG_LV(STOPF, k) = stop1;
+            PZG_LV(TKS, k) = e1;
             PZG_LV(WLO, k) = wlo;
-            // Two literals in one step (three tokens in four of config 3's streams are literals): the second is taken when it is one
-            // too and lies inside the input and the capacity -- if not, it is the next step's token, whatever it is
-            const bool lit = ok & !m0;
-            const uint32_t e2 = (tb & 1u) ? e9 : e8;  // (a literal's tb is 8 or 9)
-            const bool lit2 = lit & ((e2 & (ENT_MATCH | ENT_STOP)) == 0u) & (PZG_LV(s.P, k) + tb + (e2 & 31u) <= PZG_LV(s.END, k)) & (ob + 2u <= PZG_LV(bi.CAP, k));
-            const uint32_t adv = ok ? tb + (lit2 ? e2 & 31u : 0u) : 0u;
-            PZG_LV(s.P, k) += adv;
+            const uint32_t adv = bits_l + (arm ? tba : 0u);
+            PZG_LV(s.P, k) = pos + adv;
             PZG_LV(s.R, k) += adv;
-            // ---- the match under way (a new one, or what is left of the last)
-            const bool newm = ok & m0;
-            uint32_t ml = newm ? tlen : ml0, md = newm ? tdist : PZG_LV(s.MD, k);
-            const bool copying = run & (ml != 0u) & (fw == 0u);
-            const bool farm = copying & (md > NEAR_MAX);
-            const bool nearm = copying & !farm;
-            // near: three aligned dwords of the lane's window, funnel-shifted (OutputWindow.hs:82-101: a piece of at most `distance` bytes)
-            uint32_t nn = ml < 8u ? ml : 8u;
-            nn = nn < md ? nn : md;
-            const uint32_t src = ob - md, sdw = src >> 2, so = (src & 3u) << 3;
+            // ---- the near match under way (one that was just decoded: behind the step's literals): three aligned dwords of the
+            // lane's window, funnel-shifted (OutputWindow.hs:82-101: a piece of at most `distance` bytes, and nothing of what this
+            // step appends)
+            const uint32_t ml = arm ? mlen : ml0, md = arm ? mdist : md0;
+            const bool nearm = run & (ml != 0u) & (md <= NEAR_MAX);
+            const uint32_t room = 8u - nl, reach_b = md > nl ? md - nl : 0u;  // (nl = 0 unless the match is the step's own)
+            uint32_t nn = ml < room ? ml : room;
+            nn = nn < reach_b ? nn : reach_b;
+            nn = nearm ? nn : 0u;
+            const uint32_t src = ob + nl - md, sdw = src >> 2, so = (src & 3u) << 3;
             const uint32_t s0 = L.win[win_addr(sdw, k)], s1 = L.win[win_addr(sdw + 1u, k)], s2 = L.win[win_addr(sdw + 2u, k)];
             const uint32_t nlo = funnel(s1, s0, so), nhi = funnel(s2, s1, so);
-            // far: eight bytes (or what is left) of the stream's own output, asked for now, appended FAR_LAND steps from now
-            const uint64_t landed = PZG_LV(s.FARV[u], k);
+            // ---- a far match under way (or just decoded): the bytes behind what this step appends are asked for
             {
-                const uint8_t *fp = farm ? PZG_LV(bi.OUT, k) + src : (const uint8_t *)(const void *)common;
+                const uint32_t rem = ml - fnc;  // (fnc != 0 only while a far match is under way: ml = ml0 >= fnc)
+                const bool farq = run & (md > NEAR_MAX) & (rem != 0u);
+                const uint8_t *fp = farq ? PZG_LV(bi.OUT, k) + (ob + nl + fnc - md) : (const uint8_t *)(const void *)common;
+                const uint32_t fnew = farq ? (rem < 8u ? rem : 8u) : 0u;
 #if PZG_DEVICE_PASS
                 typedef uint64_t __attribute__((aligned(1))) u64_u;
                 PZG_LV(s.FARV[u], k) = *(const u64_u *)(const void *)fp;
 #else
                 uint64_t v = 0;
-                __builtin_memcpy(&v, fp, farm ? (ml < 8u ? ml : 8u) : 8u);  // (the model reads no byte it does not use)
+                __builtin_memcpy(&v, fp, farq ? fnew : 8u);  // (the model reads no byte it does not use)
                 PZG_LV(s.FARV[u], k) = v;
 #endif
+                PZG_LV(s.FN[u], k) = fnew;
             }
-            const uint32_t fnew = farm ? (ml < 8u ? ml : 8u) : 0u;
-            PZG_LV(s.FN[u], k) = fnew;
-            const bool land = fn != 0u;  // this slot's load of FAR_LAND steps ago is the lane's: its bytes go in now
-            PZG_LV(s.FW, k) = farm ? 1u : land ? 0u : fw;
-            // ---- the chunk: n bytes of data
-            const uint32_t n = land ? fn : nearm ? nn : lit ? (lit2 ? 2u : 1u) : 0u;
-            uint32_t dlo = land ? (uint32_t)landed : nearm ? nlo : ((tk >> 8) & 0xffu) | (e2 & 0xff00u);
-            uint32_t dhi = land ? (uint32_t)(landed >> 32) : nearm ? nhi : 0u;
+            // ---- the chunk: n bytes of data -- what the far load of the step before brought, or the step's literals with the match's
+            // bytes behind them
+            const bool land = fnc != 0u;
+            const uint64_t fv = PZG_LV(s.FARV[u ^ 1u], k);
+            const uint32_t n = land ? fnc : nl + nn;
+            const uint32_t lits = ((e1 >> 8) & 0xffu) | (e2 & 0xff00u) | ((e3 & 0xff00u) << 8);
+            const uint64_t nd = (((uint64_t)nhi << 32) | nlo) << (nl << 3);
+            uint32_t dlo = land ? (uint32_t)fv : (nl == 0u ? 0u : nl == 1u ? lits & 0xffu : nl == 2u ? lits & 0xffffu : lits & 0xffffffu) | (uint32_t)nd;
+            uint32_t dhi = land ? (uint32_t)(fv >> 32) : (uint32_t)(nd >> 32);
             {   // (bytes behind the n-th are not the chunk's)
                 const uint32_t nb = n << 3;
                 const uint32_t mlo = nb >= 32u ? 0xffffffffu : ((1u << nb) - 1u);
@@ -377,13 +396,10 @@ struct Bundle {
                 dlo &= mlo;
                 dhi &= mhi;
             }
-            const uint32_t took = (land | nearm) ? n : 0u;
-            ml -= took;
-            // (an overlapping match: what was appended repeats the pattern, so the distance may double -- Monad.hs:324-333 copies
-            // `distance` bytes at a time, which comes to the same bytes)
-            md = (nearm & (md < 8u)) ? md << 1 : md;
-            PZG_LV(s.ML, k) = ml;
-            PZG_LV(s.MD, k) = md;
+            // (an overlapping match: once a whole period is out, what was appended repeats the pattern and the distance may double --
+            // Monad.hs:324-333 copies `distance` bytes at a time, which comes to the same bytes)
+            PZG_LV(s.ML, k) = ml - (land ? fnc : nn);
+            PZG_LV(s.MD, k) = (nearm & (md < 8u) & (nn == md)) ? md << 1 : md;
             // ---- the append: the partial last dword rides in ACC; three dwords are written whatever n is (the two behind the
             // first hold the window's oldest bytes, which no near match reaches: NEAR_MAX)
             {

@@ -26,7 +26,7 @@ def _build_model(flags):
     d = os.path.join(ROOT, "tests", "model")
     so = os.path.join(d, "libpzgmodel%s.so" % ("_" + hashlib.md5(" ".join(flags).encode()).hexdigest()[:8] if flags else ""))
     srcs = [os.path.join(d, "model_harness.cpp"), os.path.join(ROOT, "pure_zlib_amd", "csrc", "inflate_core.h"),
-            os.path.join(ROOT, "pure_zlib_amd", "csrc", "wave.h")]
+            os.path.join(ROOT, "pure_zlib_amd", "csrc", "wave.h"), os.path.join(ROOT, "pure_zlib_amd", "csrc", "bundle_core.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", *flags, "-o", so, srcs[0]])
     M = C.CDLL(so)
