@@ -77,6 +77,30 @@ def traffic_from_profiles(args, ring_bits, n):
     return None, {"reason": why}
 
 
+def hetero_blob(seed):
+    """A batch of mixed KINDS: text, html, literal-heavy skewed bytes and binary-looking data, 8 / 16 / 32 / 64 KiB,
+    levels 1 / 6 / 9 -- neighbours in the batch differ in all three, so a stream-wave's profile of one stream is rarely the next one's."""
+    kind, size, level = seed % 4, [8, 16, 32, 64][(seed // 4) % 4] * 1024, [6, 1, 9][(seed // 16) % 3]
+    if kind == 0:
+        t = corpus.zipf_text(size, seed)
+    elif kind == 1:
+        t = corpus.html_slice(size, seed)
+    elif kind == 2:
+        t = corpus.skewed_bytes(size, seed)
+    else:
+        # binary-looking: 16-byte records -- a little-endian counter, a small enum, two random bytes, constants
+        rng = np.random.default_rng(0xB1A0 + seed)
+        nrec = size // 16
+        rec = np.zeros((nrec, 16), dtype=np.uint8)
+        rec[:, 0:4] = (np.arange(nrec, dtype=np.uint32) * 3 + seed).view(np.uint8).reshape(nrec, 4)
+        rec[:, 4] = rng.integers(0, 4, size=nrec)
+        rec[:, 8:10] = rng.integers(0, 256, size=(nrec, 2))
+        rec[:, 12] = 0xff
+        rec[:, 13] = rng.integers(0, 2, size=nrec) * 0x80
+        t = rec.tobytes()
+    return t, zlib.compress(t, level)
+
+
 def build_pool(args):
     """P distinct (text, zlib stream) pairs, seeds 0..P-1, identical on every rank."""
     texts, zs = [], []
@@ -102,6 +126,8 @@ def build_pool(args):
             size = 1024 * (1 + (seed * 2654435761 >> 7) % 64)
             t = corpus.zipf_text(size, seed)
             z = zlib.compress(t, 6)
+        elif args.workload == "hetero":
+            t, z = hetero_blob(seed)
         else:
             t = corpus.zipf_text(args.blob_bytes, seed)
             z = zlib.compress(t, args.level)
@@ -118,7 +144,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed", "skewed_bytes", "html", "runs", "fixed_bin"])
+    ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed", "skewed_bytes", "html", "runs", "fixed_bin", "hetero"])
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
     ap.add_argument("--blob-bytes", type=int, default=32768)
     ap.add_argument("--level", type=int, default=6)
@@ -127,6 +153,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline legs (0 = every core)")
     ap.add_argument("--adler-gib", type=float, default=16.0, help="Adler-32 microbench size (BASELINE config 2); 0 = skip")
     ap.add_argument("--ring-bits", type=int, default=0, help="LDS ring size class 11..15 (0 = library default); 15 = the whole 32 KiB window in LDS")
+    ap.add_argument("--bundles", type=int, default=-1, help="diagnostic: PZG_OPT_BUNDLES (0 off, 1 launches of 32,768 streams or more, 2 always; -1 = library default)")
     ap.add_argument("--no-ab", action="store_true", help="skip the secondary measurement of the pure 32 KiB LDS-ring variant")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--gzip", action="store_true", help="diagnostic: the same payloads as RFC 1952 members (extension; CRC-32 pass on the device)")
@@ -224,6 +251,8 @@ def main():
     from pure_zlib_amd import _ffi
     ring_bits = args.ring_bits or int(os.environ.get("PZG_RING_BITS", _ffi.DEFAULT_RING_BITS))
     ctx.set_ring_bits(ring_bits)
+    if args.bundles >= 0:
+        ctx.set_bundles(args.bundles)
 
     def step():
         ctx.decompress_many_device(d_in.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), d_out.data_ptr(),
@@ -235,8 +264,11 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    cold_ms = None
+    for w in range(args.warmup):
         step()
+        if w == 0:  # the process' FIRST launch: scratch as the allocator left it -- no stream-wave has a profile, no run-up has adapted
+            cold_ms = ctx.last_kernel_ms()
     torch.cuda.synchronize()
     kernel_ms = []
     barrier()
@@ -359,6 +391,7 @@ def main():
                               "dynamic-Huffman zlib blobs per GPU, one stream per wavefront",
                     "fixed_4k": f"BASELINE config 3: {args.streams} x 4 KiB fixed-Huffman (Z_FIXED level-1) blobs per GPU",
                     "mixed": f"BASELINE config 5 shape: {args.streams} mixed 1-64 KiB level-6 blobs per GPU",
+                    "hetero": f"diagnostic: {args.streams} blobs of mixed KINDS (text / html / literal-heavy / binary-looking, 8-64 KiB, levels 1 / 6 / 9) per GPU",
                     "skewed_bytes": f"diagnostic: {args.streams} x {args.blob_bytes // 1024} KiB literal-heavy skewed-byte blobs, level {args.level}",
                     "fixed_bin": f"diagnostic: {args.streams} x 4 KiB fixed-Huffman blobs of text with the high bit set (every literal a 9-bit code)",
                     "runs": f"diagnostic: {args.streams} x {args.blob_bytes // 1024} KiB byte runs / short repeating patterns (overlapping matches), level {args.level}",
@@ -391,6 +424,8 @@ def main():
                 "read_only_GBps": round(comp_total / (k_ms * 1e-3) / 1e9, 2),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms_avg": round(k_ms, 4),
+                "cold_first_launch_kernel_ms": None if cold_ms is None else round(cold_ms, 4),
+                "cold_first_launch_GiBps": None if cold_ms is None else round(int(out_cap.sum()) / (cold_ms * 1e-3) / 2**30, 2),
                 "verified_step_kernel_ms": None if verify_ms is None else round(verify_ms, 4),
                 "traffic": traffic_from_profiles(args, ring_bits, n)[0],
                 "traffic_source": traffic_from_profiles(args, ring_bits, n)[1],
@@ -407,9 +442,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_variants and args.workload == "l6_32k":
         from devbatch import DeviceBatch
 
-        def variant(name, what, texts_v, zs_v, count, seed):
+        def variant(name, what, texts_v, zs_v, count, seed, profile=None):
             pick_v = np.random.default_rng(seed).integers(0, len(zs_v), size=count)
             vb = DeviceBatch(texts_v, zs_v, pick_v, dev=local_rank)
+            if profile is not None:
+                ctx.set_profile(profile)
             ok_v = True
             try:
                 vb.check_all(*vb.run(ctx, ring_bits))  # (poisons the arenas first; raises on any difference)
@@ -429,6 +466,9 @@ def main():
                             "algorithmic_bytes_per_launch": dec_b + comp_b, "achieved_GBps": round((dec_b + comp_b) / (k * 1e-3) / 1e9, 2),
                             "frac": round((dec_b + comp_b) / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bit_exact": ok_v,
                             "verified": "every stream: status, length, in_used, Adler-32, every byte (poisoned arenas)"}
+            if profile is not None:
+                result[name]["profile"] = "on" if profile else "off (PZG_OPT_PROFILE 0: pieces of equal length)"
+                ctx.set_profile(True)
             del vb
             torch.cuda.empty_cache()
             return ok_v
@@ -447,6 +487,13 @@ def main():
         tv = [corpus.zipf_text(65536, 5000 + s_) for s_ in range(npv)]
         zv = [zlib.compress(t_, 6) for t_ in tv]
         v_ok &= variant("blob_64k_variant", "SURVEY.md 8d: 32,768 x 64 KiB level-6 blobs (same code path, ring wrap)", tv, zv, 32768, 0xC6)
+        # ... and a batch of mixed KINDS, with the stream-waves' profiles on and off: what the headline's "strips of equal work" are worth
+        # when the streams of a batch do NOT resemble one another
+        hv = [hetero_blob(s_) for s_ in range(min(args.pool, 768))]
+        tv, zv = [h[0] for h in hv], [h[1] for h in hv]
+        what_h = "32,768 blobs of mixed kinds: text / html / literal-heavy / binary-looking, 8-64 KiB, levels 1 / 6 / 9"
+        v_ok &= variant("hetero_variant", what_h, tv, zv, 32768, 0xC7, profile=True)
+        v_ok &= variant("hetero_variant_profile_off", what_h, tv, zv, 32768, 0xC7, profile=False)
         if not v_ok:
             bit_exact = False
             result["bit_exact"] = False

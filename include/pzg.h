@@ -184,9 +184,15 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
 /* PZG_OPT_BUNDLES (0.5): 1 (default) -- a PZG_DEVICE_PTRS launch of 32,768 or more zlib streams first takes its streams of the
  *   FIXED code (what `compressobj(1, ..., Z_FIXED)` and level-1 encoders make of short records) 64 to a wavefront, one lane per
  *   stream; every other stream, and every stream that is not plain (another block type, any error, a stream or capacity of a MiB or
- *   more), is decoded by the ordinary one-stream-per-wavefront kernel as before.  2 -- launches of any size.  0 -- off.  Results never
- *   depend on it; it needs no scratch memory. */
+ *   more), is decoded by the ordinary one-stream-per-wavefront kernel as before; a launch in which no stream turned out to be one for
+ *   the bundles lets the next 2, 6, 14 ... 64 launches of the context go without looking (the look costs such a launch ~1 %).
+ *   2 -- launches of any size, always looking.  0 -- off.  Results never depend on it; it needs no scratch memory. */
 #define PZG_OPT_BUNDLES 4
+/* PZG_OPT_PROFILE (0.5): 1 (default) -- a stream-wave of a PZG_DEVICE_PTRS launch remembers where the tokens of the last stream it
+ *   decoded lay and cuts the next stream's input into pieces of equal WORK there (checked against the stream itself before it is
+ *   trusted); 0 -- pieces of equal length, always.  Results never depend on it: it is there to be measured (bench.py's
+ *   hetero_variant reports both).  Takes effect launch by launch. */
+#define PZG_OPT_PROFILE 5
 PZG_API int  pzg_set_option(pzg_ctx *ctx, int option, int64_t value);
 /* The only environment variable the library reads is PZG_RING_BITS (11..15): the default of PZG_OPT_RING_BITS for
  * contexts created afterwards. */

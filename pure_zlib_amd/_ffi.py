@@ -42,6 +42,7 @@ OPT_RING_BITS = 1
 OPT_HOST_THREADS = 2
 OPT_SCRATCH_BYTES = 3
 OPT_BUNDLES = 4
+OPT_PROFILE = 5
 DEFAULT_RING_BITS = 11
 
 # every symbol include/pzg.h declares

@@ -75,6 +75,7 @@ struct CallThread {
 struct Arena {
     void *p = nullptr;
     size_t cap = 0;
+    bool prof_off = false;  // (a strips' scratch) its waves' profiles are switched off: PZG_OPT_PROFILE
 };
 struct Pinned {
     uint8_t *p = nullptr;
@@ -119,6 +120,12 @@ struct Shard {
     Arena a_gz[COUNTER_SLOTS], a_order[COUNTER_SLOTS];
     // ... and the kernels' token scratch (hundreds of MiB for a launch that fills the chip): STRIP_SLOTS of them, a launch
     // that takes one in use waits (on its own stream) for the launch that used it last
+    // bundles (pzg_bundle_kernel.h): what the last probing launch found, fetched behind it -- a launch that decoded no stream by
+    // bundles (a batch of dynamic-code streams) lets the next 2, 6, 14 ... 64 launches go without the probe
+    uint32_t *h_bundle = nullptr;  // page-locked: [0] streams the last probing launch decoded by bundles
+    hipEvent_t ev_bundle = nullptr;
+    bool bundle_pending = false;
+    uint32_t bundle_skip = 0, bundle_backoff = 0;
     Arena a_strip[STRIP_SLOTS];
     hipEvent_t ev_strip[STRIP_SLOTS] = {};
     bool strip_used[STRIP_SLOTS] = {};
@@ -143,6 +150,7 @@ struct pzg_ctx {
     std::unique_ptr<Helpers> helpers;
     std::atomic<uint64_t> scratch_cap{0};  // PZG_OPT_SCRATCH_BYTES: the kernels' scratch per device, at most (0: no limit)
     std::atomic<int> bundles{1};           // PZG_OPT_BUNDLES
+    std::atomic<int> profile{1};           // PZG_OPT_PROFILE
 };
 
 namespace {
@@ -214,6 +222,7 @@ void strip_for_launch(pzg_ctx *ctx, Arena &a, int num_cus, uint32_t n, uint32_t 
         }
         a.p = q;
         a.cap = (want + 255u) & ~(size_t)255u;
+        a.prof_off = false;  // (as the allocator left it: no profile yet)
     }
     args.strip = (uint32_t *)a.p;
     args.strip_waves = (uint32_t)(want / per_wave);
@@ -325,6 +334,11 @@ int shard_create(pzg_ctx *ctx, int device, std::unique_ptr<Shard> &out)
     if (hipMalloc((void **)&sh->d_counters, 256 * COUNTER_SLOTS) != hipSuccess) return PZG_RC_NO_MEMORY;
     for (int k = 0; k < STRIP_SLOTS; ++k)
         if (hipEventCreateWithFlags(&sh->ev_strip[k], hipEventDisableTiming) != hipSuccess) return PZG_RC_NO_DEVICE;
+    if (hipEventCreateWithFlags(&sh->ev_bundle, hipEventDisableTiming) != hipSuccess) return PZG_RC_NO_DEVICE;
+    if (hipHostMalloc((void **)&sh->h_bundle, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        sh->h_bundle = nullptr;  // (tolerated: every launch probes)
+    }
     out = std::move(sh);
     (void)ctx;
     return PZG_RC_OK;
@@ -344,6 +358,8 @@ void shard_destroy(Shard &sh)
         if (sh.a_strip[k].p) (void)hipFree(sh.a_strip[k].p);
         if (sh.ev_strip[k]) (void)hipEventDestroy(sh.ev_strip[k]);
     }
+    if (sh.h_bundle) (void)hipHostFree(sh.h_bundle);
+    if (sh.ev_bundle) (void)hipEventDestroy(sh.ev_bundle);
     if (sh.d_counters) (void)hipFree(sh.d_counters);
     if (sh.ev0) (void)hipEventDestroy(sh.ev0);
     if (sh.ev1) (void)hipEventDestroy(sh.ev1);
@@ -417,11 +433,39 @@ int launch_device(pzg_ctx *ctx, Shard &sh, pzg::InflateArgs a, uint32_t flags)
 #if defined(PZG_LAB)  // lab builds only: the windows alone
     if (getenv("PZG_NO_STRIPS")) a.strip = nullptr;
 #endif
+    if (a.strip && sh.a_strip[ss].prof_off != (ctx->profile.load() == 0)) {  // PZG_OPT_PROFILE changed since this scratch was last used
+        const bool off = ctx->profile.load() == 0;
+        HIP_TRY(ctx, pzg::launch_profile_switch(a.strip, (uint32_t)(sh.a_strip[ss].cap / pzg::inflate_strip_wave_bytes()), off, sh.stream));
+        sh.a_strip[ss].prof_off = off;
+    }
     a.bundle = (ctx->bundles.load() == 2 || (ctx->bundles.load() == 1 && a.n >= BUNDLE_MIN_STREAMS)) && !(flags & PZG_GZIP) && !a.dict_len ? 1u : 0u;
+    if (a.bundle && ctx->bundles.load() == 1 && sh.h_bundle) {
+        // (the probe costs a launch of dynamic-code streams ~1 %: the bundle kernel, and two words every stream-wave reads first)
+        if (sh.bundle_pending && hipEventQuery(sh.ev_bundle) == hipSuccess) {
+            sh.bundle_pending = false;
+            if (sh.h_bundle[0] == 1u) {  // (the count + 1: see pzg_inflate_kernel.h)
+                sh.bundle_backoff = sh.bundle_backoff >= 31u ? 64u : 2u * sh.bundle_backoff + 2u;
+                sh.bundle_skip = sh.bundle_backoff;
+            } else {
+                sh.bundle_backoff = 0u;
+            }
+        }
+        if (sh.bundle_skip != 0u) {
+            sh.bundle_skip -= 1u;
+            a.bundle = 0u;
+        } else if (!sh.bundle_pending) {
+            sh.h_bundle[0] = 0u;
+            a.bundle_report = sh.h_bundle;  // (page-locked host memory: the device writes it over the link)
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(sh.ev0, sh.stream));
     HIP_TRY(ctx, pzg::launch_inflate(a, ctx->ring_bits, sh.num_cus, sh.stream));
     HIP_TRY(ctx, hipEventRecord(sh.ev1, sh.stream));
     HIP_TRY(ctx, hipEventRecord(sh.ev_strip[ss], sh.stream));
+    if (a.bundle_report) {  // what the probe found (written by the launch's last kernel), for the launches to come
+        HIP_TRY(ctx, hipEventRecord(sh.ev_bundle, sh.stream));
+        sh.bundle_pending = true;
+    }
     sh.strip_used[ss] = true;
     sh.timed = true;
     sh.last_was_host = false;
@@ -1044,6 +1088,10 @@ int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
     }
     if (option == PZG_OPT_SCRATCH_BYTES && value >= 0) {  // (takes effect launch by launch: an arena larger than its share is given back when next used)
         ctx->scratch_cap.store((uint64_t)value);
+        return PZG_RC_OK;
+    }
+    if (option == PZG_OPT_PROFILE && (value == 0 || value == 1)) {
+        ctx->profile.store((int)value);
         return PZG_RC_OK;
     }
     if (option == PZG_OPT_BUNDLES && value >= 0 && value <= 2) {

@@ -11,8 +11,8 @@
 namespace pzg {
 
 // counter words of a launch (InflateArgs::counter): [0] the ordinary kernel's stream index, [1] streams handed back to the
-// fixup pass, [3] streams the bundles left to the ordinary kernel; [16..19]: what the bundles' idle lanes read
-enum : uint32_t { CTR_TODO = 3, CTR_COMMON = 16 };
+// fixup pass, [3] streams the bundles left to the ordinary kernel, [4] streams they decoded; [16..19]: what the bundles' idle lanes read
+enum : uint32_t { CTR_TODO = 3, CTR_CLEAN = 4, CTR_COMMON = 16 };
 
 __global__ __launch_bounds__(64, 1) void bundle_kernel(InflateArgs a)
 {
@@ -54,8 +54,9 @@ __global__ __launch_bounds__(64, 1) void bundle_kernel(InflateArgs a)
             a.status[i] = ST_BUNDLE_TODO;
         }
     }
-    const uint64_t todo = __builtin_amdgcn_ballot_w64(have && !clean);
+    const uint64_t todo = __builtin_amdgcn_ballot_w64(have && !clean), done = __builtin_amdgcn_ballot_w64(have && clean);
     if (lane == 0u && todo != 0ull) atomicAdd(a.counter + CTR_TODO, (uint32_t)__builtin_popcountll(todo));
+    if (lane == 0u && done != 0ull) atomicAdd(a.counter + CTR_CLEAN, (uint32_t)__builtin_popcountll(done));
 }
 
 }  // namespace pzg

@@ -50,13 +50,53 @@ __device__ __forceinline__ LaunchArgs launch_args()
     return kp;
 }
 
+#if defined(PZG_LAB) && defined(PZG_LAB_SEED_PROFILE)
+// Lab builds only (tests/test_gpu_parity.py: the persistent profile, fuzzed on the device -- VERDICT r5 item 5): before stream i the
+// wave's profile words are overwritten with a well-marked profile that no stream ever taught it -- random, unsorted, decreasing,
+// constant, squeezed or stretched quantiles, odd extents and token counts (one stream in eight keeps what the wave learnt).
+__device__ __forceinline__ void lab_seed_profile(uint32_t *prof, uint32_t i)
+{
+    const uint32_t lane = threadIdx.x, kind = i & 7u;
+    uint64_t z = ((uint64_t)i << 8 | lane) * 0x9E3779B97F4A7C15ull + 0x5EED0006ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    const uint32_t r = (uint32_t)(z >> 32);
+    if (kind == 7u) return;
+    uint32_t q = r;
+    if (kind == 1u) q = r & 0x3ffffu;
+    else if (kind == 2u) q = lane * ((i >> 3) % 4000u + 1u);
+    else if (kind == 3u) q = (63u - lane) * 1000u;
+    else if (kind == 4u) q = (i >> 3) % 3u == 0u ? 0u : 4095u;
+    else if (kind == 5u) q = lane == (i >> 3) % 63u + 1u ? (i & 8u ? 0u : 0xffffffffu) : lane * 1000u;
+    else if (kind == 6u) q = 0u;
+    prof[lane] = q;
+    if (lane < 5u) {
+        const uint32_t q63 = kind == 2u ? 63u * ((i >> 3) % 4000u + 1u) : kind == 5u ? 63000u : kind == 3u || kind == 6u ? 0u : kind == 4u ? q : 0x3ffffu;
+        const uint32_t xs[4] = {q63 + 1u, 1u << 18, q63 + 5000u, q63}, ts[4] = {64u, 5000u, 64u * 192u, 64u * 192u + 1u};
+        const uint32_t w = lane == 0u ? xs[(i >> 3) & 3u] : lane == 1u ? ts[(i >> 5) & 3u] : lane == 2u ? 0x51DF0A7Eu : 0u;
+        prof[64u + lane] = kind == 0u ? r : w;
+    }
+}
+#endif
+
 template <int RING_BITS, bool FIXUP, bool GZIP = false>
 __global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_kernel(InflateArgs)
 {
     __shared__ WaveLds<RING_BITS> lds;
+    if (FIXUP && !GZIP && blockIdx.x == 0 && threadIdx.x == 0 && launch_args()->bundle_report)  // (the launch's last kernel: see pzg_api.cpp launch_device)
+        *launch_args()->bundle_report = 1u + __hip_atomic_load(launch_args()->counter + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (FIXUP && __builtin_nontemporal_load(launch_args()->counter + 1) == 0u) return;  // nothing was handed back
     // (bundles, pzg_bundle_kernel.h: the launch's small streams of the fixed code are done; word 3 counts what was left to this kernel)
-    if (!FIXUP && !GZIP && launch_args()->bundle != 0u && __builtin_nontemporal_load(launch_args()->counter + 3) == 0u) return;
+    // (... and word 4 what they decoded: with nothing decoded -- a batch of other streams -- no stream's status is looked at below)
+    bool filter = false;
+    if (!FIXUP && !GZIP && launch_args()->bundle != 0u) {
+        // (uni(): a value that comes out of a vector load is lane-dependent to the compiler, and ONE lane-dependent branch in the
+        // stream loop sends the whole loop through its structurizer -- see inflate_core.h hot_loop)
+        // (device-scope loads, served by the L2: as non-temporal loads -- 6,656 waves asking one memory channel for the same word
+        // twice -- they cost the launch 130 us, measured)
+        if (uni(__hip_atomic_load(launch_args()->counter + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) return;
+        filter = uni(__hip_atomic_load(launch_args()->counter + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u;
+    }
     if (threadIdx.x == 0) lds.fixed_ready = 0u;  // LDS is not zeroed at launch
     __syncthreads();
     // Persistent stream-waves: the grid is sized to the residency of the chip and every wave pulls
@@ -76,7 +116,10 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_k
 #endif
             // FIXUP pass (32 KiB ring): only the streams a small-ring launch handed back
             if (FIXUP && a->status[i] != ST_RETRY_FULL_RING) continue;
-            if (!FIXUP && !GZIP && a->bundle != 0u && a->status[i] != ST_BUNDLE_TODO) continue;  // a bundle's stream: done
+            if (!FIXUP && !GZIP && filter) {  // a bundle's stream: done
+                asm volatile("" ::: "memory");  // (or the load is hoisted in front of the test: a trip to memory per stream, measured)
+                if (uni((uint32_t)a->status[i]) != (uint32_t)ST_BUNDLE_TODO) continue;
+            }
             Decoder<RING_BITS, GZIP> dec(lds);
             if (!FIXUP && a->strip && blockIdx.x < a->strip_waves) dec.strip = a->strip + (size_t)blockIdx.x * Decoder<RING_BITS, GZIP>::STRIP_WORDS;
             const uint8_t *dict = nullptr;
@@ -86,6 +129,13 @@ __global__ __launch_bounds__(64, waves_per_simd(RING_BITS, GZIP)) void inflate_k
                 dict = a->dict_base + a->dict_off[i];
                 dict_len = dl > 0xffffffffull ? 0xffffffffu : (uint32_t)dl;
             }
+#if defined(PZG_LAB) && defined(PZG_LAB_SEED_PROFILE)
+            if (dec.strip) {
+                static_assert(Decoder<RING_BITS, GZIP>::PROF_MAGIC == 0x51DF0A7Eu, "lab_seed_profile marks its profiles with the kernel's word");
+                lab_seed_profile(dec.strip + Decoder<RING_BITS, GZIP>::PROF_OFF, i);
+                __syncthreads();
+            }
+#endif
             dec.run(a->in_base + a->in_off[i], a->in_len[i], a->out_base + a->out_off[i], a->out_cap[i], &r, dict, dict_len);
 #if defined(PZG_PROFILE)
             // diagnostic build: the 16 phase counters of stream i go to prof_out[16*i ..]

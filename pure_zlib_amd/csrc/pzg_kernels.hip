@@ -176,6 +176,29 @@ size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip
 }
 size_t inflate_strip_wave_bytes() { return (size_t)Decoder<11>::STRIP_WORDS * sizeof(uint32_t); }
 
+// PZG_OPT_PROFILE: word 67 of a wave's profile counts the streams for which it is not to be consulted (strip_profile_layout): all
+// ones and a magic word -- "a profile is there, leave it alone for the next four billion streams" -- switches it off; zero switches
+// it on again (what the wave learnt in between is still there: strip_profile_learn goes on writing the quantiles)
+__global__ __launch_bounds__(256) void profile_switch_kernel(uint32_t *strip, uint32_t waves, uint32_t off)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= waves) return;
+    uint32_t *p = strip + (size_t)w * Decoder<11>::STRIP_WORDS + Decoder<11>::PROF_OFF;
+    if (off) {
+        p[66] = Decoder<11>::PROF_MAGIC;
+        p[67] = 0xffffffffu;
+    } else {
+        p[67] = 0u;
+        p[68] = 0u;
+    }
+}
+hipError_t launch_profile_switch(uint32_t *strip, uint32_t waves, bool off, hipStream_t stream)
+{
+    if (waves == 0u) return hipSuccess;
+    hipLaunchKernelGGL(profile_switch_kernel, dim3((waves + 255u) / 256u), dim3(256), 0, stream, strip, waves, off ? 1u : 0u);
+    return hipGetLastError();
+}
+
 hipError_t launch_inflate(const InflateArgs &a_in, int ring_bits, int num_cus, hipStream_t stream)
 {
     if (a_in.n == 0) return hipSuccess;
@@ -187,6 +210,9 @@ hipError_t launch_inflate(const InflateArgs &a_in, int ring_bits, int num_cus, h
         hipLaunchKernelGGL(bundle_kernel, dim3((a.n + 63u) / 64u), dim3(64), 0, stream, a);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+#if defined(PZG_LAB) && defined(PZG_LAB_BUNDLE_NOFLAG)  // (lab: what the bundle kernel's mere presence costs the kernel behind it)
+        a.bundle = 0u;
+#endif
     }
     const uint32_t waves = launch_waves(ring_bits, num_cus, a.n, a.gzip);
     dim3 grid(waves), block(64);

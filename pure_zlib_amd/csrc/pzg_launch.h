@@ -34,6 +34,7 @@ struct InflateArgs {
     // bundles (round 6; pzg_bundle_kernel.h): nonzero -- the launch's small streams of the fixed code are decoded 64 to a wave, one
     // lane per stream, before the ordinary kernel takes what is left.  zlib streams without dictionaries only.
     uint32_t bundle;
+    uint32_t *bundle_report;  // null, or a word of page-locked HOST memory: the launch's last kernel leaves 1 + the streams the bundles decoded there
 };
 
 // one batched call of the resumable decoder (decompressIncremental): decoder i continues from its ResumeState
@@ -75,6 +76,9 @@ uint32_t resume_launch_waves(int num_cus, uint32_t n);  // workgroups of a launc
 hipError_t launch_inflate(const InflateArgs &a, int ring_bits, int num_cus, hipStream_t stream);
 size_t inflate_strip_bytes(int ring_bits, int num_cus, uint32_t n, uint32_t gzip);  // what InflateArgs::strip holds when every stream-wave of that launch owns a slice
 size_t inflate_strip_wave_bytes();  // ... one stream-wave's slice
+// the profiles of `waves` stream-wave slices of a strips' scratch switched off (no stream consults or counts down its wave's profile
+// from then on) or on again (inflate_core.h strip_profile_layout: the words behind the quantiles)
+hipError_t launch_profile_switch(uint32_t *strip, uint32_t waves, bool off, hipStream_t stream);
 // the gzip instances (pzg_kernels_b.hip): `waves` workgroups of the ring's kernel, or of the fixup pass
 hipError_t launch_inflate_gzip(const InflateArgs &a, int ring_bits, bool fixup, uint32_t waves, hipStream_t stream);
 

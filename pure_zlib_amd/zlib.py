@@ -206,6 +206,10 @@ class Context:
         (0: never, 1: launches of 32,768 streams or more -- the default, 2: always).  Results are identical."""
         _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_BUNDLES, int(mode)), self._h)
 
+    def set_profile(self, on: bool):
+        """PZG_OPT_PROFILE: the stream-waves' memory of where the last stream's tokens lay (default on).  Results are identical."""
+        _ffi.check(self._L.pzg_set_option(self._h, _ffi.OPT_PROFILE, 1 if on else 0), self._h)
+
     def sync(self):
         _ffi.check(self._L.pzg_sync(self._h), self._h)
 

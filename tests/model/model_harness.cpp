@@ -26,6 +26,14 @@ static uint32_t crc32_bits(const uint8_t *p, uint64_t n)
     return ~reg;
 }
 
+// the scratch a model "wave" keeps from one stream to the next (its profile is in it: strip_profile_learn)
+template <int RB, bool GZ>
+static uint32_t *&kept_scratch()
+{
+    static uint32_t *kept = nullptr;
+    return kept;
+}
+
 template <int RB, bool GZ = false>
 static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t cap, pzm_result *r)
 {
@@ -41,7 +49,7 @@ static void run_one(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t c
     // the wave's token scratch (strips); PZM_NO_STRIPS=1 in the environment: the windows alone, as on a launch without scratch
     // (it outlives the call, as a persistent wave's scratch outlives its streams: the wave's profile -- strip_profile_learn() -- is in it;
     // PZM_FRESH_SCRATCH=1: a new one, filled with garbage, every call)
-    static uint32_t *kept = nullptr;
+    uint32_t *&kept = kept_scratch<RB, GZ>();
     const bool fresh = getenv("PZM_FRESH_SCRATCH") != nullptr;
     uint32_t *strip = nullptr;
     if (!getenv("PZM_NO_STRIPS")) {
@@ -221,6 +229,24 @@ int pzm_bundle(const uint8_t *const *ins, const uint64_t *in_lens, uint8_t *cons
     }
     for (uint32_t k = 0; k < n; ++k) free(bufs[k]);
     free(lds);
+    return 0;
+}
+
+// Test hook: overwrite the profile words of the ring's kept scratch -- 80 dwords from PROF_OFF on: 64 quantiles,
+// the span's extent, its token count, the magic word (pass pzm_profile_magic() for a profile the kernel will trust), the streams
+// to skip, the back-off level -- so that the next stream is laid out by them.
+uint32_t pzm_profile_magic(void) { return pzg::Decoder<11>::PROF_MAGIC; }
+int pzm_poke_profile(int ring_bits, const uint32_t *words)
+{
+    if (ring_bits != 11 && ring_bits != 15) return -1;
+    uint32_t *&kept = ring_bits == 11 ? kept_scratch<11, false>() : kept_scratch<15, false>();
+    const size_t n = ring_bits == 11 ? pzg::Decoder<11>::STRIP_WORDS : pzg::Decoder<15>::STRIP_WORDS;
+    const size_t off = ring_bits == 11 ? pzg::Decoder<11>::PROF_OFF : pzg::Decoder<15>::PROF_OFF;
+    if (!kept) {
+        kept = (uint32_t *)malloc(sizeof(uint32_t) * n);
+        memset(kept, 0xC3, sizeof(uint32_t) * n);
+    }
+    memcpy(kept + off, words, 80 * sizeof(uint32_t));
     return 0;
 }
 

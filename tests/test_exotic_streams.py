@@ -20,7 +20,7 @@ POOR_FLAGS = ["-DPZG_STRIP_BACK=8", "-DPZG_STRIP_ROUNDS=2"]  # the strips' run-u
 def lab_library(tag, flags):
     """build/lab_<tag>/libpzg.so: the product's sources with extra -D options (tests/tools/lab_build.sh), rebuilt when a source is newer."""
     so = os.path.join(ROOT, "build", "lab_" + tag, "libpzg.so")
-    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "wave.h", "pzg_inflate_kernel.h", "pzg_kernels.hip", "pzg_kernels_b.hip", "pzg_launch.h", "pzg_helpers.h", "pzg_api.cpp",
+    srcs = [os.path.join(ROOT, "pure_zlib_amd", "csrc", f) for f in ("inflate_core.h", "bundle_core.h", "wave.h", "pzg_inflate_kernel.h", "pzg_bundle_kernel.h", "pzg_kernels.hip", "pzg_kernels_b.hip", "pzg_launch.h", "pzg_helpers.h", "pzg_api.cpp",
                                                                     "pzg_errors.cpp", "pzg.map")] + [os.path.join(ROOT, "include", "pzg.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call([os.path.join(ROOT, "tests", "tools", "lab_build.sh"), tag, *flags])
@@ -115,6 +115,16 @@ def test_lab_library_without_call_threads_builds():
     """build/lab_nothreads/libpzg.so (for tests/test_gpu_api.py::test_host_paths_when_no_thread_can_be_started) builds here and
     travels to the GPU box with the snapshot."""
     so = lab_library("nothreads", NOTHREADS_FLAGS)
+    assert b"hipv4-amdgcn-amd-amdhsa--gfx950" in open(so, "rb").read()
+
+
+PROFSEED_FLAGS = ["-DPZG_LAB", "-DPZG_LAB_SEED_PROFILE"]  # every stream is laid out by a well-marked profile that no stream taught the wave
+
+
+def test_lab_library_with_seeded_profiles_builds():
+    """build/lab_profseed/libpzg.so (for tests/test_gpu_parity.py::test_strips_laid_out_by_fuzzed_profiles_on_the_device) builds here and
+    travels to the GPU box with the snapshot."""
+    so = lab_library("profseed", PROFSEED_FLAGS)
     assert b"hipv4-amdgcn-amd-amdhsa--gfx950" in open(so, "rb").read()
 
 

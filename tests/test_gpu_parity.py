@@ -264,6 +264,53 @@ print("poor strips parity ok", len(streams))
     assert out.returncode == 0 and "poor strips parity ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
 
 
+def test_strips_laid_out_by_fuzzed_profiles_on_the_device(tmp_path):
+    """the wave's profile lives in library scratch that outlives streams and launches, and steers how a span's strips
+    are cut.  build/lab_profseed/libpzg.so (tests/tools/lab_build.sh -DPZG_LAB -DPZG_LAB_SEED_PROFILE; built on the CPU side by
+    tests/test_exotic_streams.py) overwrites the profile words before EVERY stream with a well-marked profile that no stream taught the
+    wave -- random, unsorted, decreasing, constant, squeezed, stretched, with odd extents and token counts: text, html and literal-heavy
+    streams of 20-70 KiB (the ones a profile is consulted for), writer-made and strip-case streams, valid and corrupted, rings 11 and 15,
+    three launches, against the oracle -- in a child process (PZG_LIB)."""
+    import sys
+    from test_exotic_streams import PROFSEED_FLAGS, lab_library
+    so = lab_library("profseed", PROFSEED_FLAGS)
+    code = r'''
+import os, sys, zlib
+sys.path.insert(0, os.path.join(os.environ["PZG_ROOT"], "tests")); sys.path.insert(0, os.environ["PZG_ROOT"])
+import torch; torch.cuda.init()
+import corpus, deflate_writer as W
+import pure_zlib_amd as P
+from pure_zlib_amd import _ffi
+from oracle import oracle as O
+assert _ffi.LIB_PATH.endswith("build/lab_profseed/libpzg.so"), _ffi.LIB_PATH
+ctx = P.Context(0)
+streams = []
+for seed in range(160):
+    n = [20000, 32768, 50000, 70000][seed % 4]
+    d = [corpus.zipf_text, corpus.html_slice, corpus.skewed_bytes][seed % 3](n, seed)
+    streams.append(zlib.compress(d, [6, 1, 9][seed % 3]))
+for seed in range(24):
+    z = W.exotic_stream(seed)[1] if seed % 2 else corpus.strip_case(seed)[1]
+    streams.append(z)
+    streams.append(corpus.corrupt(z, seed * 16))
+exp = [O.decompress(z, 1 << 21) for z in streams]
+for ring in (11, 15):
+    ctx.set_ring_bits(ring)
+    for launch in range(3):
+        got = P.decompress_many(streams, ctx=ctx)
+        for k, (g, (r, o)) in enumerate(zip(got, exp)):
+            if r.status == 0:
+                assert g == P.Right(o), (ring, launch, k)
+            else:
+                assert (not g.is_right()) and g.value.show() == r.message.decode(), (ring, launch, k, g, r.message)
+ctx.close()
+print("fuzzed profiles parity ok", len(streams))
+'''
+    env = dict(os.environ, PZG_LIB=so, PZG_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "fuzzed profiles parity ok" in out.stdout, (out.returncode, out.stdout[-1500:], out.stderr[-3000:])
+
+
 def test_text_blobs_with_far_back_references(ctx, oracle):
     """32-100 KiB Zipf text: distances up to 32 KiB, i.e. older than every hybrid ring."""
     streams, datas = [], []

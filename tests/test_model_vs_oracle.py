@@ -346,6 +346,26 @@ def test_model_incremental_spans_of_strips(model_lib, oracle, rb):
             assert bytes(dec.total) == oo
 
 
+@pytest.mark.parametrize("rb", [12, 15])
+def test_model_incremental_resumes_mid_block_with_long_distance_codes(model_lib, oracle, rb):
+    """a call that resumes in the middle of a block runs strip_span(), which asks whether the DISTANCE code has second-level
+    tables (dist_sub_used) -- a word the ResumeState did not carry.  Writer-made streams whose distance codes are 13-15 bits long in
+    constant use, in pieces of 5,000 and 9,000 bytes: every call but the first resumes inside the one long block, with input enough
+    for a span; whole event traces and every byte against the oracle's."""
+    import deflate_writer as W
+    for seed in (0, 8, 16, 1, 9):
+        d, z, _ = W.exotic_stream(seed)
+        for step, room in ((5000, 70000), (9000, 40000)):
+            pieces = [z[i:i + step] for i in range(0, len(z), step)]
+            eo, ro, oo = oracle.trace(pieces)
+            dec = ModelDecoder(model_lib, room, rb)
+            for p in pieces:
+                if not dec.feed(p):
+                    break
+            assert dec.events == eo, (seed, step, room, ro.status)
+            assert ro.status == 0 and bytes(dec.total) == oo == d
+
+
 def test_model_incremental_bad_header_with_fdict_bit(model_lib, oracle):
     """Zlib.hs:53-67: CMF and FLG are read and checked (FCHECK, method, window) before anything else; a bad header whose FDICT
     bit is set is a DecompError after two bytes, not a NeedMore waiting for a DICTID."""
@@ -423,3 +443,61 @@ def test_model_queue_never_overfills(model, rb):
         z = zlib.compress(d, 6)
         r, out = model(z, len(d), rb)
         assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), seed
+
+
+def test_model_profile_fuzz(model, oracle):
+    """the wave's profile (strip_profile_layout / _check / _learn) lives in scratch that outlives streams and
+    launches and is trusted when its magic word is there.  Before every stream the profile words are overwritten -- random words; the
+    magic with random, non-monotone, constant, decreasing or extreme quantiles, extents and token counts; a sound profile stretched or
+    squeezed -- and the stream must still decode to the oracle's bytes: a layout can cost rounds, never a token."""
+    import random
+    M = C.CDLL(os.path.join(ROOT, "tests", "model", "libpzgmodel.so"))
+    M.pzm_profile_magic.restype = C.c_uint32
+    M.pzm_poke_profile.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
+    magic = M.pzm_profile_magic()
+    rng = random.Random(0xF022)
+    pool = []
+    for seed in range(24):
+        n = [20000, 32768, 50000, 70000][seed % 4]
+        d = [corpus.zipf_text, corpus.html_slice, corpus.skewed_bytes][seed % 3](n, seed)
+        pool.append((d, zlib.compress(d, [6, 1, 9][seed % 3])))
+    exp = [oracle.decompress(z, len(d)) for d, z in pool]
+    for it in range(1000):
+        kind = it % 8
+        q = [0] * 80
+        xt = rng.choice([64, 500, 8000, 30000, 100000, 1 << 18, (1 << 18) + 1, 0xffffffff])
+        if kind == 0:
+            q = [rng.getrandbits(32) for _ in range(80)]
+        elif kind == 1:  # random quantiles under the magic
+            q[:64] = [rng.randrange(0, 1 << 18) for _ in range(64)]
+        elif kind == 2:  # sorted, but starting anywhere / with plateaus
+            q[:64] = sorted(rng.randrange(0, xt % (1 << 19) + 1) for _ in range(64))
+            if rng.random() < 0.5:
+                q[0] = 0
+        elif kind == 3:  # decreasing
+            q[:64] = sorted((rng.randrange(0, 1 << 17) for _ in range(64)), reverse=True)
+        elif kind == 4:  # constant
+            q[:64] = [rng.choice([0, 1, 4095, 1 << 17])] * 64
+        elif kind == 5:  # a sound shape, squeezed into the first bits or stretched far beyond any stream
+            scale = rng.choice([1, 3, 100, 4000])
+            q[:64] = [k * scale for k in range(64)]
+        elif kind == 6:  # one quantile out of order in an otherwise sound profile
+            q[:64] = [k * 1000 for k in range(64)]
+            j = rng.randrange(1, 64)
+            q[j] = rng.choice([0, q[j - 1] - 1, 0xffffffff, 1 << 31])
+        else:            # zeros
+            pass
+        if kind != 0:
+            q[64] = rng.choice([xt, q[63] + 1, q[63], q[63] + rng.randrange(1, 5000)]) & 0xffffffff
+            q[65] = rng.choice([0, 63, 64, 5000, 64 * 192, 64 * 192 + 1, 0xffffffff])
+            q[66] = magic
+            q[67] = rng.choice([0, 0, 0, 1, 0xffffffff])
+            q[68] = rng.choice([0, 0, 31, 32, 0xffffffff])
+        arr = (C.c_uint32 * 80)(*[w & 0xffffffff for w in q])
+        rb = 11 if it % 5 else 15
+        assert M.pzm_poke_profile(rb, arr) == 0
+        k = rng.randrange(len(pool))
+        d, z = pool[k]
+        r, out = model(z, len(d), rb)
+        ro, oo = exp[k]
+        assert same(ro, oo, r, out) and out == d, (it, kind, k, rb, r.status)

@@ -50,15 +50,19 @@ def main():
         elif wl == "html":
             t = corpus.html_slice(32768, seed)
             z = zlib.compress(t, 6)
+        elif wl == "hetero_bin":  # the binary-looking kind of bench.py's hetero workload (16-byte records)
+            sys.path.insert(0, ROOT)
+            import bench
+            t, z = bench.hetero_blob(4 * seed + 3)
         elif wl == "skewed_bytes":
             t = corpus.skewed_bytes(32768, seed)
             z = zlib.compress(t, 6)
         else:
             t = corpus.zipf_text(32768, seed)
             z = zlib.compress(t, 6)
-        out = C.create_string_buffer(len(t))
+        out = C.create_string_buffer(len(t) + 16)
         r = R()
-        assert M.pzm_decompress(z, len(z), out, len(t), 11, C.byref(r)) == 0 and r.status == 0 and out.raw == t
+        assert M.pzm_decompress(z, len(z), out, len(t), 11, C.byref(r)) == 0 and r.status == 0 and out.raw[:len(t)] == t
         tot_out += len(t)
         tot_in += len(z)
     v = M.pzm_stats()
