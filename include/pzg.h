@@ -296,6 +296,11 @@ typedef struct pzg_decoder pzg_decoder;
 PZG_API int  pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out);  /* takes a reference on ctx */
 PZG_API void pzg_decoder_destroy(pzg_decoder *dec);  /* legal before or after pzg_shutdown(ctx); NULL is ignored */
 PZG_API int  pzg_decoder_reset(pzg_decoder *dec, const uint32_t *idx, uint32_t m);  /* those decoders start a new stream */
+/* (0.5) What the last LARGE pzg_decoder_feed call of `dec` (512 decoders or 64 MiB of rooms and more: the pipelined path) spent where, in
+ * milliseconds: [0] the whole call; [1] packing the inputs into page-locked staging (the issuing thread); [2] waiting for the ranges'
+ * kernels, [3] bringing down what their decoders delivered (a second thread); [4] copying it out into the caller's rooms (a third).
+ * The three threads run side by side: the parts do not add up to the call.  -1: no such call yet. */
+PZG_API int  pzg_decoder_last_feed_ms(pzg_decoder *dec, double out[5]);
 PZG_API int  pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m,
                       const uint8_t *in_base, const uint64_t *in_off, const uint64_t *in_len, const uint8_t *final_in,
                       uint8_t *out_base, const uint64_t *out_off, const uint64_t *out_cap,

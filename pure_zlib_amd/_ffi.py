@@ -48,7 +48,7 @@ DEFAULT_RING_BITS = 11
 # every symbol include/pzg.h declares
 SYMBOLS = [
     "pzg_init", "pzg_init_mask", "pzg_init_devices", "pzg_host_alloc", "pzg_host_free", "pzg_device_count", "pzg_adler32_many", "pzg_decompress_many_dict", "pzg_decompress_many_sharded",
-    "pzg_decoder_create", "pzg_decoder_destroy", "pzg_decoder_reset", "pzg_decoder_feed", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
+    "pzg_decoder_create", "pzg_decoder_destroy", "pzg_decoder_reset", "pzg_decoder_feed", "pzg_decoder_last_feed_ms", "pzg_shutdown", "pzg_set_stream", "pzg_reset_stream", "pzg_set_option", "pzg_sync", "pzg_decompress_many", "pzg_decompress",
     "pzg_adler32", "pzg_error_message", "pzg_last_kernel_ms", "pzg_strerror", "pzg_last_error", "pzg_version",
 ]
 
@@ -119,6 +119,8 @@ def lib():
     L.pzg_decoder_reset.restype = C.c_int
     L.pzg_decoder_feed.argtypes = [C.c_void_p, u32p, C.c_uint32, vp, u64p, u64p, vp, vp, u64p, u64p, u64p, i32p, u32p, u64p, u32p, u32p]
     L.pzg_decoder_feed.restype = C.c_int
+    L.pzg_decoder_last_feed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.pzg_decoder_last_feed_ms.restype = C.c_int
     L.pzg_decompress.argtypes = [C.c_void_p, vp, C.c_uint64, vp, C.c_uint64, u64p, i32p, u32p, u64p]
     L.pzg_decompress.restype = C.c_int
     L.pzg_adler32.argtypes = [C.c_void_p, vp, C.c_uint64, C.c_uint32, u32p, C.c_uint32]

@@ -56,6 +56,7 @@ def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_deco
         out_off = np.arange(n_decoders, dtype=np.uint64) * np.uint64(room)
         out_buf = np.zeros(n_decoders * room + 16, dtype=np.uint8)
         t_calls, n_calls, n_feeds, out_full = 0.0, 0, 0, 0
+        parts_ms, parts_n, up_b, down_b = np.zeros(5), 0, 0, 0
         while not done.all():
             active = np.nonzero(~done)[0]
             m = len(active)
@@ -86,6 +87,12 @@ def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_deco
             _ffi.check(rc, ctx.handle)
             n_calls += 1
             n_feeds += m
+            lf = (C.c_double * 5)()
+            if L.pzg_decoder_last_feed_ms(h, lf) == 0 and lf[0] >= 0 and m >= 512:  # (the pipelined path: what the call spent where)
+                parts_ms += np.array(list(lf))
+                parts_n += 1
+                up_b += int(in_len.sum())
+                down_b += int(o_len.sum())
             for j, k in enumerate(active):
                 outs[k] += out_buf[int(out_off[j]):int(out_off[j]) + int(o_len[j])].tobytes()
                 tails[k] = parts[j][int(used[j]):]
@@ -101,7 +108,14 @@ def incremental_throughput(ctx, streams: List[bytes], plain: List[bytes], n_deco
         return {"decoders": n_decoders, "piece_bytes": piece, "room_bytes": room, "feed_calls": n_calls, "decoder_feeds": n_feeds,
                 "out_full_resumes": out_full, "decoded_MiB": round(total / 2**20, 1), "seconds_in_feed_calls": round(t_calls, 4),
                 "GiBps": round(total / t_calls / 2**30, 2), "ms_per_feed_call": round(t_calls / n_calls * 1e3, 2),
-                "us_per_decoder_feed": round(t_calls / n_feeds * 1e6, 2), "ok": bool(ok)}
+                "us_per_decoder_feed": round(t_calls / n_feeds * 1e6, 2), "ok": bool(ok),
+                "per_call_ms": None if parts_n == 0 else {
+                    "call": round(parts_ms[0] / parts_n, 2), "packing_inputs": round(parts_ms[1] / parts_n, 2),
+                    "waiting_for_kernels": round(parts_ms[2] / parts_n, 2), "downloads": round(parts_ms[3] / parts_n, 2),
+                    "copy_out": round(parts_ms[4] / parts_n, 2), "MiB_up": round(up_b / parts_n / 2**20, 1), "MiB_down": round(down_b / parts_n / 2**20, 1),
+                    "link_ms_at_57GBps": round((up_b + down_b) / parts_n / 57e9 * 1e3, 2),
+                    "note": "pzg_decoder_last_feed_ms, mean over the pass' pipelined feed calls: packing runs on the issuing thread, the waits "
+                            "and downloads on a second, the copy-out on a third -- side by side, so the parts do not add up to the call"}}
 
     try:
         first = one_pass()  # (its feed calls also allocate and page-lock the library's staging for this many decoders: not a measurement)

@@ -1316,6 +1316,8 @@ struct pzg_decoder {
     hipStream_t s_kr[MAXR] = {};  // a launch stream per range: a range's decoders fill a sixth of the chip, the ranges' kernels run side by side
     hipEvent_t ev_up[MAXR] = {}, ev_k[MAXR] = {}, ev_res[MAXR] = {}, ev_dat[MAXR] = {};
     bool pipe_ready = false;
+    // what the last large feed spent where, in ms (pzg_decoder_last_feed_ms): the call | packing | waiting for the ranges' kernels | downloads | copy-out
+    double last_feed[5] = {-1.0, -1.0, -1.0, -1.0, -1.0};
     std::mutex mu;
 };
 
@@ -1341,6 +1343,14 @@ int decoder_pipe_prepare(pzg_ctx *ctx, pzg_decoder *d)
 }  // namespace
 
 extern "C" {
+
+int pzg_decoder_last_feed_ms(pzg_decoder *dec, double out[5])
+{
+    if (!dec || !out) return PZG_RC_BAD_ARG;
+    std::lock_guard<std::mutex> g(dec->mu);
+    for (int k = 0; k < 5; ++k) out[k] = dec->last_feed[k];
+    return PZG_RC_OK;
+}
 
 int pzg_decoder_create(pzg_ctx *ctx, uint32_t n, pzg_decoder **out)
 {
@@ -1631,17 +1641,16 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
             hipError_t derr = hipSuccess;
 #if defined(PZG_LAB)
             const bool trace = getenv("PZG_TRACE_HOST") != nullptr;
+#endif
+            // (a handful of clock reads per range: what pzg_decoder_last_feed_ms reports)
             const auto t_feed0 = std::chrono::steady_clock::now();
             auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
             double t_pack = 0, t_res = 0, t_dat = 0, t_out = 0;
-#endif
             // one fetched range handed to the caller (results into the caller's arrays, bytes out of the staging)
             auto copy_one = [&](uint32_t c) {
                 const uint32_t j0 = lo[c], j1 = lo[c + 1];
                 if (j0 == j1) return;
-#if defined(PZG_LAB)
                 const auto t0 = std::chrono::steady_clock::now();
-#endif
                 uint64_t delivered = 0;
                 for (uint32_t j = j0; j < j1; ++j) {
                     out_len[j] = olen[j];
@@ -1660,31 +1669,23 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                     for (uint32_t j = j0 + (uint32_t)((uint64_t)nn * part / nparts), e2 = j0 + (uint32_t)((uint64_t)nn * (part + 1) / nparts); j < e2; ++j)
                         if (olen[j]) memcpy(out_base + out_off[j], hout + doff[j], olen[j] <= ocap[j] ? olen[j] : ocap[j]);
                 });
-#if defined(PZG_LAB)
                 t_out += ms_since(t0);
-#endif
             };
             // one issued range fetched: wait for its results, bring down what its decoders delivered
             auto fetch_one = [&](uint32_t c) -> hipError_t {
                 const uint32_t j0 = lo[c], j1 = lo[c + 1];
                 if (j0 == j1) return hipSuccess;
-#if defined(PZG_LAB)
                 auto t0 = std::chrono::steady_clock::now();
-#endif
                 hipError_t e = hipEventSynchronize(dec->ev_res[c]);
-#if defined(PZG_LAB)
                 t_res += ms_since(t0);
                 t0 = std::chrono::steady_clock::now();
-#endif
                 uint64_t delivered = 0;  // the decoders of the range packed their bytes behind one another from ooff[j0] on (whole 16-byte vectors each)
                 for (uint32_t j = j0; j < j1 && e == hipSuccess; ++j) delivered += pad16(olen[j]);
                 if (e == hipSuccess && delivered != 0) {
                     e = hipMemcpyAsync(hout + ooff[j0], (const uint8_t *)dec->d_dense.p + ooff[j0], delivered, hipMemcpyDeviceToHost, dec->s_dat);
                     if (e == hipSuccess) e = hipStreamSynchronize(dec->s_dat);
                 }
-#if defined(PZG_LAB)
                 t_dat += ms_since(t0);
-#endif
                 return e;
             };
             // The second and third thread of the call (joined whatever way the call ends; an exception inside one -- the helpers'
@@ -1751,16 +1752,12 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                 if (j0 != j1) {
                     const uint32_t nn = j1 - j0;
                     const size_t ib = (j1 < m ? ioff[j1] : ip) - ioff[j0];
-#if defined(PZG_LAB)
                     const auto tp0 = std::chrono::steady_clock::now();
-#endif
                     ctx->helpers->run(ib >= (4u << 20) ? ctx->helpers->size() : 1u, [&](unsigned part, unsigned nparts) {
                         for (uint32_t j = j0 + (uint32_t)((uint64_t)nn * part / nparts), e2 = j0 + (uint32_t)((uint64_t)nn * (part + 1) / nparts); j < e2; ++j)
                             if (ilen[j]) memcpy(hin + ioff[j], in_base + in_off[j], ilen[j]);
                     });
-#if defined(PZG_LAB)
                     t_pack += ms_since(tp0);
-#endif
                     if (ib) FEED_TRY(hipMemcpyAsync((uint8_t *)dec->d_in.p + ioff[j0], hin + ioff[j0], ib, hipMemcpyHostToDevice, dec->s_up));
                     FEED_TRY(hipEventRecord(dec->ev_up[c], dec->s_up));
                     hipStream_t s_k = dec->s_kr[c];
@@ -1806,6 +1803,11 @@ int pzg_decoder_feed(pzg_decoder *dec, const uint32_t *idx, uint32_t m, const ui
                     if (derr == hipSuccess) copy_one(c);  // (an exception here is the issuing thread's: the call's own catch reports it)
                 }
             }
+            dec->last_feed[0] = ms_since(t_feed0);
+            dec->last_feed[1] = t_pack;
+            dec->last_feed[2] = t_res;
+            dec->last_feed[3] = t_dat;
+            dec->last_feed[4] = t_out;
 #if defined(PZG_LAB)
             if (trace)
                 fprintf(stderr, "[pzg] feed: %u decoders, %.1f MiB in, %.1f MiB of rooms: %.1f ms (issuing thread: packing %.1f; draining thread: waiting for "
