@@ -46,6 +46,14 @@ struct Bundle {
     static constexpr uint32_t BQ_PAIRS = BundleLds::BQ_PAIRS, WIN_DW = BundleLds::WIN_DW, WIN_BYTES = 4u * WIN_DW;
     static constexpr uint32_t NEAR_MAX = WIN_BYTES - 16u; // a distance up to this is read from the window (the append may clobber the 12 oldest bytes)
     static constexpr uint32_t PHASE = 4u;                 // steps between two looks at the rings and the flushes
+#ifndef PZG_BUNDLE_BQ_LOW
+#define PZG_BUNDLE_BQ_LOW 5
+#endif
+    // A lane with fewer pairs than this in its ring at a phase's start has the rings refilled.  A step consumes 49 bits at the most and
+    // moves a lane on once at the most: four pairs a phase -- with five, the pair a lane looks at next (NXT) has always been written.
+    // (Four, and NXT read again after a refill: 5 % slower, measured -- an LDS read right behind the refill's writes.)
+    static constexpr uint32_t BQ_LOW = PZG_BUNDLE_BQ_LOW;
+    static_assert(BQ_LOW >= PHASE + 1u && BQ_LOW <= BQ_PAIRS, "the ring never runs dry inside a phase");
     static constexpr uint32_t TK_MATCH = ENT_MATCH;
 
     struct In {                            // lane k's stream (ON = 0: none)
@@ -166,7 +174,7 @@ struct Bundle {
                 PZG_LANES_BEGIN(k)
                     const uint32_t st = PZG_LV(s.ST, k);
                     PZG_LV(LIVE, k) = (st == (uint32_t)BS_RUN) | (st == (uint32_t)BS_FIN);
-                    PZG_LV(LOW, k) = (st == (uint32_t)BS_RUN) & (PZG_LV(s.WR, k) - PZG_LV(s.RD, k) < BQ_PAIRS / 2u);
+                    PZG_LV(LOW, k) = (st == (uint32_t)BS_RUN) & (PZG_LV(s.WR, k) - PZG_LV(s.RD, k) < BQ_LOW);
                 PZG_LANES_END
                 if (lanes_ballot(LIVE) == 0ull) break;
 #if PZG_DEVICE_PASS
@@ -178,9 +186,6 @@ struct Bundle {
                 if (lanes_ballot(LOW) != 0ull) {
                     PZG_LANES_BEGIN(k)
                         refill(PZG_LV(s.SP, k), PZG_LV(s.MAXDW, k), L.bq, k, PZG_LV(s.NX, k), PZG_LV(s.RD, k), PZG_LV(s.WR, k));
-                        // (a lane that moved on four times in the last phase -- 49 bits a step is the most a step consumes -- took its NXT
-                        // from a slot that had not been written yet: it is read again, now that the slot is)
-                        PZG_LV(s.NXT, k) = L.bq[(PZG_LV(s.RD, k) & (BQ_PAIRS - 1u)) * 64u + k];
                     PZG_LANES_END
                 }
                 flush_groups(L, bi, s);
