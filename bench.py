@@ -42,7 +42,7 @@ def kernel_sha256():
     """What the measured traffic belongs to: the kernels' source (profiles/traffic.json records it with every entry)."""
     import hashlib
     h = hashlib.sha256()
-    for fn in ("inflate_core.h", "pzg_inflate_kernel.h", "pzg_kernels.hip", "pzg_kernels_b.hip", "wave.h"):
+    for fn in ("inflate_core.h", "bundle_core.h", "pzg_inflate_kernel.h", "pzg_bundle_kernel.h", "pzg_kernels.hip", "pzg_kernels_b.hip", "wave.h"):
         with open(os.path.join(ROOT, "pure_zlib_amd", "csrc", fn), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -50,7 +50,7 @@ def kernel_sha256():
 
 def traffic_from_profiles(args, ring_bits, n):
     """HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, counters only) of
-    this same command, recorded in profiles/traffic.json after each profiling session (tests/tools/r5_profiles.sh, tests/tools/traffic_update.py) together
+    this same command, recorded in profiles/traffic.json after each profiling session (tests/tools/r6_profiles.sh, tests/tools/traffic_update.py) together
     with the SHA-256 of the kernels' source and the pool size of the run.  Returns (bytes or None, where the number comes
     from -- or WHY there is none: an entry measured on other kernel source, or with another pool, is not this kernel's traffic)."""
     try:
@@ -63,7 +63,7 @@ def traffic_from_profiles(args, ring_bits, n):
     for e in t["entries"]:
         if e["workload"] == args.workload and e["ring_bits"] == ring_bits and e["streams"] == n and bool(e.get("gzip")) == bool(args.gzip):
             if e.get("kernel_sha256") != sha:
-                why = f"the entry was measured on other kernel source (sha256 {str(e.get('kernel_sha256'))[:12]}..., this build {sha[:12]}...): re-run tests/tools/r5_profiles.sh traffic + tests/tools/traffic_update.py"
+                why = f"the entry was measured on other kernel source (sha256 {str(e.get('kernel_sha256'))[:12]}..., this build {sha[:12]}...): re-run tests/tools/r6_profiles.sh traffic + tests/tools/traffic_update.py"
                 continue
             if e.get("pool") not in (None, args.pool):
                 why = f"the entry was measured with --pool {e.get('pool')}, this run uses {args.pool}"
@@ -405,17 +405,21 @@ def main():
                 "ring_bits": ring_bits,
                 **({"container": "gzip members (extension): CRC-32 + ISIZE verified by a second kernel"} if args.gzip else {}),
                 "window": "32 KiB LDS ring" if ring_bits == 15 else f"{2**ring_bits // 1024} KiB LDS near ring + far back-references from the stream's flushed output (HBM/L2)",
-                "decode": "strips: 64 lanes decode 64 consecutive pieces of a stream's input token by token (speculative starts, verified) and write "
-                          "them as sequences (literal run + match: a record and the literal bytes) to a per-wave scratch in HBM (64.8 KiB per resident "
-                          "stream-wave, allocated by the library); then one lane copies one whole sequence inside the LDS ring, up to 64 sequences a "
-                          "group; a stream's first span is cut into strips of equal WORK by the wave's profile of the stream before it (checked by "
-                          "the run-ups); 128-bit windows for stream tails and short streams",
+                "decode": ("bundles: 64 streams of the fixed code to a wave, one lane per stream -- every lane a sequential inflater with its own 512-byte "
+                           "window in LDS (dword-interleaved), up to three literals and a match's first bytes a step, far matches from the stream's own flushed "
+                           "output; what is not plain goes to the one-stream-per-wave kernel") if args.workload in ("fixed_4k", "fixed_bin") and not args.gzip and args.bundles != 0 and n >= 32768 else
+                          ("strips: 64 lanes decode 64 consecutive pieces of a stream's input token by token, up to two literals a step (speculative starts, "
+                           "verified) and write them as sequences (literal run + match: a record and the literal bytes) to a per-wave scratch in HBM (64.8 KiB per "
+                           "resident stream-wave, allocated by the library); then one lane copies one whole sequence inside the LDS ring, up to 64 sequences a "
+                           "group; a stream's first span is cut into strips of equal WORK by the wave's profile of the stream before it (checked by "
+                           "the run-ups); 128-bit windows for stream tails and short streams"),
                 "verified": ("every stream: status, length, in_used, Adler-32 and full byte compare, on one more step run after the "
                              "timed region over POISONED output / status arrays") if bit_exact is not None else "skipped",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": f"inflate_kernel<{ring_bits},false,{str(bool(args.gzip)).lower()}>",
+                "kernel": "bundle_kernel" if args.workload in ("fixed_4k", "fixed_bin") and not args.gzip and args.bundles != 0 and n >= 32768
+                          else f"inflate_kernel<{ring_bits},false,{str(bool(args.gzip)).lower()}>",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -390,17 +390,12 @@ struct Bundle {
             const bool land = fnc != 0u;
             const uint64_t fv = PZG_LV(s.FARV[u ^ 1u], k);
             const uint32_t n = land ? fnc : nl + nn;
-            const uint32_t lits = ((e1 >> 8) & 0xffu) | (e2 & 0xff00u) | ((e3 & 0xff00u) << 8);
+            // (what lies behind the chunk's n-th byte in `data` means nothing and is not masked away: it goes to window positions that
+            // are yet to be produced, and to ACC's bytes past the position, which the next append cuts off)
+            const uint32_t lits = ubfe(((e1 >> 8) & 0xffu) | (e2 & 0xff00u) | ((e3 & 0xff00u) << 8), 0u, nl << 3);
             const uint64_t nd = (((uint64_t)nhi << 32) | nlo) << (nl << 3);
-            uint32_t dlo = land ? (uint32_t)fv : (nl == 0u ? 0u : nl == 1u ? lits & 0xffu : nl == 2u ? lits & 0xffffu : lits & 0xffffffu) | (uint32_t)nd;
-            uint32_t dhi = land ? (uint32_t)(fv >> 32) : (uint32_t)(nd >> 32);
-            {   // (bytes behind the n-th are not the chunk's)
-                const uint32_t nb = n << 3;
-                const uint32_t mlo = nb >= 32u ? 0xffffffffu : ((1u << nb) - 1u);
-                const uint32_t mhi = nb <= 32u ? 0u : nb >= 64u ? 0xffffffffu : ((1u << (nb - 32u)) - 1u);
-                dlo &= mlo;
-                dhi &= mhi;
-            }
+            const uint32_t dlo = land ? (uint32_t)fv : lits | (uint32_t)nd;
+            const uint32_t dhi = land ? (uint32_t)(fv >> 32) : (uint32_t)(nd >> 32);
             // (an overlapping match: once a whole period is out, what was appended repeats the pattern and the distance may double --
             // Monad.hs:324-333 copies `distance` bytes at a time, which comes to the same bytes)
             PZG_LV(s.ML, k) = ml - (land ? fnc : nn);
@@ -410,7 +405,7 @@ struct Bundle {
             {
                 const uint32_t sh = (ob & 3u) << 3;
                 const uint64_t x = (((uint64_t)dhi << 32) | dlo) << sh;
-                const uint32_t d0 = PZG_LV(s.ACC, k) | (uint32_t)x, d1 = (uint32_t)(x >> 32), d2 = (uint32_t)(((uint64_t)dhi << sh) >> 32);
+                const uint32_t d0 = ubfe(PZG_LV(s.ACC, k), 0u, sh) | (uint32_t)x, d1 = (uint32_t)(x >> 32), d2 = (uint32_t)(((uint64_t)dhi << sh) >> 32);
                 const uint32_t odw = ob >> 2, tbts = (ob & 3u) + n, c = tbts >> 2;
                 L.win[win_addr(odw, k)] = d0;
                 L.win[win_addr(odw + 1u, k)] = d1;

@@ -46,11 +46,18 @@ def test_config3_65536_fixed_huffman_4k_blobs(gpu_ctx, oracle):
     assert all((z[2] >> 1) & 3 == 1 for z in zs)  # BTYPE 01: fixed Huffman
     pick = np.random.default_rng(0xC3).integers(0, len(zs), size=65536)
     b = DeviceBatch(texts, zs, pick)
-    for ring in (11, 15):
-        res = b.run(gpu_ctx, ring)
-        b.check_all(*res)
-        b.check_sample_vs_oracle(oracle, 256)
-    gpu_ctx.set_ring_bits(11)
+    try:
+        # (round 6: a launch of this size takes its streams of the fixed code 64 to a wave, one lane per stream -- bundle_core.h; with
+        # PZG_OPT_BUNDLES 0 every stream goes to the one-stream-per-wave kernel as before)
+        for bundles in (1, 0):
+            gpu_ctx.set_bundles(bundles)
+            for ring in (11, 15):
+                res = b.run(gpu_ctx, ring)
+                b.check_all(*res)
+                b.check_sample_vs_oracle(oracle, 256)
+    finally:
+        gpu_ctx.set_bundles(1)
+        gpu_ctx.set_ring_bits(11)
 
 
 def test_config4_65536_level6_32k_blobs(gpu_ctx, oracle):
