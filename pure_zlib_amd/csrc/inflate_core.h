@@ -3007,21 +3007,31 @@ struct Decoder {
     PZG_FN void lds_copy4x2(const LaneVec<uint32_t> &SM, const LaneVec<uint32_t> &DM, uint64_t m0, uint64_t m1)
     {
 #if PZG_DEVICE_PASS
-        uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
+        // (round 6: the eight source bytes are read as three ALIGNED dwords and funnel-shifted into place -- three LDS instructions
+        // instead of eight byte reads: the LDS pipe is what the groups run out of, and this alone was worth 317 -> 323 GiB/s on text, 252 ->
+        // 262 on html; the writes stay bytes: neighbouring lanes' matches share dwords)
+        static_assert(RING_OFF % 4u == 0u && OFF % 8u == 0u, "aligned dwords");
+        uint32_t a, sh, d0, d1, d2, q0, q1, y0, y1;
         uint64_t sv;
-        asm volatile("s_mov_b64 %8, exec\n\t"
-                     "s_mov_b64 exec, %11\n\t"
-                     "ds_read_u8 %0, %9 offset:%c13\n\tds_read_u8 %1, %9 offset:%c14\n\tds_read_u8 %2, %9 offset:%c15\n\tds_read_u8 %3, %9 offset:%c16\n\t"
+        asm volatile("s_mov_b64 %9, exec\n\t"
                      "s_mov_b64 exec, %12\n\t"
-                     "ds_read_u8 %4, %9 offset:%c17\n\tds_read_u8 %5, %9 offset:%c18\n\tds_read_u8 %6, %9 offset:%c19\n\tds_read_u8 %7, %9 offset:%c20\n\t"
+                     "v_and_b32 %0, -4, %10\n\t"
+                     "v_lshlrev_b32 %1, 3, %10\n\t"
+                     "ds_read_b32 %2, %0 offset:%c14\n\tds_read_b32 %3, %0 offset:%c15\n\tds_read_b32 %4, %0 offset:%c16\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
-                     "ds_write_b8 %10, %7 offset:%c20\n\tds_write_b8 %10, %6 offset:%c19\n\tds_write_b8 %10, %5 offset:%c18\n\tds_write_b8 %10, %4 offset:%c17\n\t"
-                     "s_mov_b64 exec, %11\n\t"
-                     "ds_write_b8 %10, %3 offset:%c16\n\tds_write_b8 %10, %2 offset:%c15\n\tds_write_b8 %10, %1 offset:%c14\n\tds_write_b8 %10, %0 offset:%c13\n\t"
-                     "s_mov_b64 exec, %8"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&s"(sv)
-                     : "v"(SM.v), "v"(DM.v), "s"(m0), "s"(m1), "n"(RING_OFF + OFF), "n"(RING_OFF + OFF + 1u), "n"(RING_OFF + OFF + 2u),
-                       "n"(RING_OFF + OFF + 3u), "n"(RING_OFF + OFF + 4u), "n"(RING_OFF + OFF + 5u), "n"(RING_OFF + OFF + 6u), "n"(RING_OFF + OFF + 7u)
+                     "v_alignbit_b32 %5, %3, %2, %1\n\t"
+                     "v_alignbit_b32 %6, %4, %3, %1\n\t"
+                     "v_lshrrev_b32 %7, 8, %5\n\t"
+                     "v_lshrrev_b32 %8, 8, %6\n\t"
+                     "s_mov_b64 exec, %13\n\t"
+                     "ds_write_b8_d16_hi %11, %8 offset:%c24\n\tds_write_b8_d16_hi %11, %6 offset:%c23\n\tds_write_b8 %11, %8 offset:%c22\n\tds_write_b8 %11, %6 offset:%c21\n\t"
+                     "s_mov_b64 exec, %12\n\t"
+                     "ds_write_b8_d16_hi %11, %7 offset:%c20\n\tds_write_b8_d16_hi %11, %5 offset:%c19\n\tds_write_b8 %11, %7 offset:%c18\n\tds_write_b8 %11, %5 offset:%c17\n\t"
+                     "s_mov_b64 exec, %9"
+                     : "=&v"(a), "=&v"(sh), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(q0), "=&v"(q1), "=&v"(y0), "=&v"(y1), "=&s"(sv)
+                     : "v"(SM.v), "v"(DM.v), "s"(m0), "s"(m1), "n"(RING_OFF + OFF), "n"(RING_OFF + OFF + 4u), "n"(RING_OFF + OFF + 8u),
+                       "n"(RING_OFF + OFF), "n"(RING_OFF + OFF + 1u), "n"(RING_OFF + OFF + 2u), "n"(RING_OFF + OFF + 3u), "n"(RING_OFF + OFF + 4u),
+                       "n"(RING_OFF + OFF + 5u), "n"(RING_OFF + OFF + 6u), "n"(RING_OFF + OFF + 7u)
                      : "memory");
 #else
         LaneVec<Quad> A, B;
@@ -3042,21 +3052,30 @@ struct Decoder {
                               const LaneVec<uint32_t> &D3, uint64_t m3)
     {
 #if PZG_DEVICE_PASS
-        uint32_t r0, r1, r2, r3, r4, r5, r6;
+        // (round 6: a lane is in ONE of the two masks -- one source and one destination per lane, two aligned dwords read and
+        // funnel-shifted, four byte writes: six LDS instructions where seven byte reads and seven byte writes made fourteen; with the
+        // trips' dword reads, text 318 -> 330 GiB/s, html 252 -> 273)
+        uint32_t sa, da, a, sh, d0, d1, q, y;
         uint64_t sv;
-        asm volatile("s_mov_b64 %7, exec\n\t"
-                     "s_mov_b64 exec, %12\n\t"
-                     "ds_read_u8 %0, %8 offset:%c14\n\tds_read_u8 %1, %8 offset:%c15\n\tds_read_u8 %2, %8 offset:%c16\n\tds_read_u8 %3, %8 offset:%c17\n\t"
-                     "s_mov_b64 exec, %13\n\t"
-                     "ds_read_u8 %4, %10 offset:%c14\n\tds_read_u8 %5, %10 offset:%c15\n\tds_read_u8 %6, %10 offset:%c16\n\t"
+        asm volatile("s_mov_b64 %8, exec\n\t"
+                     "s_or_b64 exec, %13, %14\n\t"
+                     "v_cndmask_b32_e64 %0, %11, %9, %13\n\t"
+                     "v_cndmask_b32_e64 %1, %12, %10, %13\n\t"
+                     "v_and_b32 %2, -4, %0\n\t"
+                     "v_lshlrev_b32 %3, 3, %0\n\t"
+                     "ds_read_b32 %4, %2 offset:%c15\n\tds_read_b32 %5, %2 offset:%c19\n\t"
                      "s_waitcnt lgkmcnt(0)\n\t"
-                     "ds_write_b8 %11, %6 offset:%c16\n\tds_write_b8 %11, %5 offset:%c15\n\tds_write_b8 %11, %4 offset:%c14\n\t"
-                     "s_mov_b64 exec, %12\n\t"
-                     "ds_write_b8 %9, %3 offset:%c17\n\tds_write_b8 %9, %2 offset:%c16\n\tds_write_b8 %9, %1 offset:%c15\n\tds_write_b8 %9, %0 offset:%c14\n\t"
-                     "s_mov_b64 exec, %7"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&s"(sv)
-                     : "v"(ST.v), "v"(DT.v), "v"(S3.v), "v"(D3.v), "s"(m4), "s"(m3), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u)
-                     : "memory");
+                     "v_alignbit_b32 %6, %5, %4, %3\n\t"
+                     "v_lshrrev_b32 %7, 8, %6\n\t"
+                     "s_mov_b64 exec, %13\n\t"
+                     "ds_write_b8_d16_hi %1, %7 offset:%c18\n\t"
+                     "s_or_b64 exec, %13, %14\n\t"
+                     "ds_write_b8_d16_hi %1, %6 offset:%c17\n\tds_write_b8 %1, %7 offset:%c16\n\tds_write_b8 %1, %6 offset:%c15\n\t"
+                     "s_mov_b64 exec, %8"
+                     : "=&v"(sa), "=&v"(da), "=&v"(a), "=&v"(sh), "=&v"(d0), "=&v"(d1), "=&v"(q), "=&v"(y), "=&s"(sv)
+                     : "v"(ST.v), "v"(DT.v), "v"(S3.v), "v"(D3.v), "s"(m4), "s"(m3), "n"(RING_OFF), "n"(RING_OFF + 1u), "n"(RING_OFF + 2u), "n"(RING_OFF + 3u),
+                       "n"(RING_OFF + 4u)
+                     : "memory", "scc");
 #else
         LaneVec<Quad> A, B;
         for (uint32_t j = 0; j < 64u; ++j)
