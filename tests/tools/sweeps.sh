@@ -7,10 +7,12 @@ run() {
     python -c "import json,sys;d=json.loads(sys.stdin.read());print('$*', '->', d['value'], 'GiB/s kernel_ms', d.get('kernel_ms', d['ms_per_step']), 'bit_exact', d.get('bit_exact'))" | tee -a "$out"
 }
 run --workload fixed_4k
+run --workload fixed_4k --bundles 0
+run --workload fixed_bin
+run --workload hetero --streams 32768
 run --workload mixed
 run --workload html
 run --workload skewed_bytes
-run --workload fixed_bin
 run --workload runs
 run --workload mixed --streams 131072
 run --workload l6_32k --gzip
