@@ -173,8 +173,11 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
 /* PZG_OPT_HOST_THREADS: helper threads (1..256) that pack / copy out the STAGED host-pointer path and the decoders' feeds
  *   (default: the machine's hardware threads, at most 24).  Set it while no host-pointer call is running. */
 #define PZG_OPT_HOST_THREADS 2
-/* PZG_OPT_SCRATCH_BYTES: upper bound, per device, on the scratch memory the LIBRARY allocates for its inflate kernels (0, the
- *   default: no bound).  A launch's stream-waves decode long runs of input through a scratch of 64.8 KiB each -- 421 MiB for a
+/* PZG_OPT_SCRATCH_BYTES: upper bound, per SHARD of the context, on the scratch memory the LIBRARY allocates for its inflate kernels
+ *   (0, the default: no bound).  A shard is one entry of the device list the context was made with: pzg_init / pzg_init_mask name
+ *   every device once, so that there the bound is per device; a pzg_init_devices list that names one physical device k times
+ *   makes k shards of it, each with its own arenas -- the ceiling on that device is k x the bound -- and every pzg_decoder object
+ *   adds one arena of one share (bound / 6) on top: with d decoders alive the ceiling is (k + d / 6) x the bound.  A launch's stream-waves decode long runs of input through a scratch of 64.8 KiB each -- 421 MiB for a
  *   launch that fills an MI355X (6,656 stream-waves) -- and a context keeps up to six such arenas per device, grow-only: two for
  *   device-pointer launches (overlapping launches must not share one) and one per host-path pipeline (four), 2.5 GiB at the
  *   most; a pzg_decoder object keeps one more for its feeds (at most 4,096 stream-waves: 259 MiB).  With a bound every arena gets an even share (bound / 6): only as many stream-waves as fit own a slice, the others

@@ -2710,6 +2710,9 @@ struct Decoder {
         stopper = false;
         const int64_t av = br.avail();
         if (av < (int64_t)(64u * STRIP_CMIN + 192u)) return STRIP_NA;
+        // (resumable instance, ADVICE r5: a span is cut to the call's room only AFTER it has been decoded -- with room for a few strips'
+        // output or less the run-up and phase B would be thrown away call after call: the windows produce what still fits)
+        if (RES && cap < op + 1024u + 4096u) return STRIP_NA;
         // A lane decodes at most STRIP_TMAX tokens (its region holds no more; phase B counts its steps).  No strip of STRIP_TMAX x the
         // block's shortest literal/length code bits can hold more -- but that bound is far from what a strip does hold (text: codes
         // from 4 bits, 6.7 bits per token), and a 32 KiB stream took two spans and two run-ups where one does.  So the strips are as
@@ -3548,17 +3551,26 @@ struct Decoder {
         if (RES) {
             // The reference hands out one 32 KiB chunk when its window holds 64 KiB or more, looked at after every MATCH
             // (account_tokens): in a group that is the first match that ends at or behind the mark -- at most one: the window
-            // then holds less again for the rest of the group's <= SEQ_GLIM bytes.
-            LaneVec<bool> FIRE;
-            PZG_LANES_BEGIN(j)
-                PZG_LV(FIRE, j) = ow + (PZG_LV(ENDX, j) & 0xffffu) >= 65536u;
-            PZG_LANES_END
-            const uint64_t fire = lanes_ballot(FIRE) & hasm;
-            ow += run;
-            if (fire != 0ull) {
-                ow -= 32768u;
-                chunks += 1u;
+            // then holds less again for the rest of the group's <= SEQ_GLIM bytes ...
+            // (... unless the window held 96 KiB or more when the group began -- 32 KiB or more of literals inside one
+            // block, which add to it without a look -- : then the matches that follow hand out a chunk EACH, one after the other, until it
+            // holds less than 64 KiB again: counted match by match, as account_tokens() does)
+            uint64_t later = hasm;  // the matches that have not been looked at yet
+            uint32_t fired = 0u;
+            for (;;) {
+                LaneVec<bool> FIRE;
+                PZG_LANES_BEGIN(j)
+                    PZG_LV(FIRE, j) = ow + (PZG_LV(ENDX, j) & 0xffffu) >= 65536u + 32768u * fired;
+                PZG_LANES_END
+                const uint64_t fire = lanes_ballot(FIRE) & later;
+                if (fire == 0ull) break;
+                fired += 1u;
+                const uint32_t at = ctz64(fire);
+                later = at >= 63u ? 0ull : later & (~0ull << (at + 1u));  // the next chunk is the next match's to hand out
             }
+            ow += run;
+            ow -= 32768u * fired;
+            chunks += fired;
         }
         op += run;
         PZG_SEQ_ACC(6, tq);

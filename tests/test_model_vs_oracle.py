@@ -366,6 +366,42 @@ def test_model_incremental_resumes_mid_block_with_long_distance_codes(model_lib,
             assert ro.status == 0 and bytes(dec.total) == oo == d
 
 
+@pytest.mark.parametrize("rb", [12, 15])
+def test_model_incremental_several_chunks_inside_one_group(model_lib, oracle, rb):
+    """the reference runs moveWindow after every MATCH (Deflate.hs:106-120) and hands out ONE 32 KiB chunk per call
+    (OutputWindow.hs:45-54) -- literals only add to its window.  A block of ~58 KiB with matches, then 44 KiB of nothing but literals,
+    then a few matches close together -- the window holds ~100 KiB when they come, and the first TWO of them hand out a chunk each,
+    inside one group of the strips' emit -- and nothing but literals from there to the end of the stream: no later match makes up for a
+    chunk the group did not count.  Whole event traces against the oracle's."""
+    import random
+    import deflate_writer as W
+    for seed in range(6):
+        rng = random.Random(0xC4 + seed)
+        out = bytearray()
+        b = W.Block("dynamic")
+        alpha = W._alphabet(rng, "text")
+        b.tokens = W.gen_tokens(rng, out, 56000 + 1500 * seed, dict(alphabet=alpha, lens=[3, 4, 5, 8, 20], dists="near", p_match=0.4))
+        b.tokens += W.gen_tokens(rng, out, 44000 + 1000 * seed, dict(alphabet=alpha, lens=[3], dists="near", p_match=0.0))
+        b.tokens += W.gen_tokens(rng, out, 12 + 5 * seed, dict(alphabet=alpha, lens=[3, 4, 6], dists="near", p_match=1.0))
+        b.tokens += W.gen_tokens(rng, out, 6000 + 4000 * (seed & 1), dict(alphabet=alpha, lens=[3], dists="near", p_match=0.0))
+        b.opts = {}
+        w = W.BitWriter()
+        W.write_block(w, b, True, rng, dict(codes="huffman", rle="rle"))
+        d = bytes(out)
+        z = bytes([0x78, 0x9c]) + w.bytes() + zlib.adler32(d).to_bytes(4, "big")
+        # (the end of a block looks at the window as well, Deflate.hs:47: the first piece ends inside the literals behind the matches)
+        for k in (600, 1500, 2800):
+            pieces = [z[:len(z) - k], z[len(z) - k:]]
+            eo, ro, oo = oracle.trace(pieces)
+            assert [e[0] for e in eo] == ["NeedMore", "Chunk", "Chunk", "NeedMore", "Chunk", "Done"]
+            dec = ModelDecoder(model_lib, 300000, rb)
+            for pc in pieces:
+                if not dec.feed(pc):
+                    break
+            assert ro.status == 0 and dec.events == eo, (seed, len(pieces), dec.events, eo)
+            assert bytes(dec.total) == oo == d
+
+
 def test_model_incremental_bad_header_with_fdict_bit(model_lib, oracle):
     """Zlib.hs:53-67: CMF and FLG are read and checked (FCHECK, method, window) before anything else; a bad header whose FDICT
     bit is set is a DecompError after two bytes, not a NeedMore waiting for a DICTID."""
