@@ -88,16 +88,7 @@ def hetero_blob(seed):
     elif kind == 2:
         t = corpus.skewed_bytes(size, seed)
     else:
-        # binary-looking: 16-byte records -- a little-endian counter, a small enum, two random bytes, constants
-        rng = np.random.default_rng(0xB1A0 + seed)
-        nrec = size // 16
-        rec = np.zeros((nrec, 16), dtype=np.uint8)
-        rec[:, 0:4] = (np.arange(nrec, dtype=np.uint32) * 3 + seed).view(np.uint8).reshape(nrec, 4)
-        rec[:, 4] = rng.integers(0, 4, size=nrec)
-        rec[:, 8:10] = rng.integers(0, 256, size=(nrec, 2))
-        rec[:, 12] = 0xff
-        rec[:, 13] = rng.integers(0, 2, size=nrec) * 0x80
-        t = rec.tobytes()
+        t = corpus.binary_records(size, seed)  # binary-looking: 16-byte records
     return t, zlib.compress(t, level)
 
 

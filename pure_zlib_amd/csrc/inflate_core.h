@@ -1032,7 +1032,7 @@ struct Decoder {
         // more scalar instructions per header (text would lose 1 % to them: it keeps the uniform tables).  If the depths
         // do not fit they are capped at the largest value that does (dcap); if two entries per prefix do not fit either,
         // only the first np_fit prefixes get a table.
-        uint32_t np_fit = 0, sub0 = 0, dcap = 0, sub_total = 0, sb = 0;
+        uint32_t np_fit = 0, sub0 = 0, dcap = 0, dup = 0, sub_total = 0, sb = 0;
         bool uniform = true;
         if (TREE != TREE_CODELEN) {
             sub0 = TREE == TREE_DIST ? lit_sub_used : 0u;
@@ -1083,12 +1083,21 @@ struct Decoder {
                 if (sub_total > pool) {  // (dcap == 1: two entries per prefix)
                     np_fit = pool >> 1;
                     sub_total = np_fit << 1;
+                } else if (dcap < SUB_DEPTH_MAX) {
+                    // (round 6) What the cap leaves of the pool goes to the first prefixes it cut short, one level each: a code that
+                    // needed 254 entries of 252 lost ALL its 10-bit symbols to decode_long() -- binary-looking records, 256 literals of
+                    // 8 to 10 bits: 900 checked steps per 30 KiB stream, every span ended by one -- where it now loses a few.
+                    uint32_t deep = 0u;
+                    for (uint32_t d = dcap + 1u; d <= SUB_DEPTH_MAX; ++d) deep += per_depth[d];
+                    dup = (pool - sub_total) >> dcap;
+                    if (dup > deep) dup = deep;
+                    sub_total += dup << dcap;
                 }
             }
             if (TREE == TREE_DIST) dist_sub_used = sub_total;
             if (TREE == TREE_LITLEN) {
                 lit_sub_used = sub_total;
-                use_sub = np_fit >= SUB_MIN_PREFIXES ? 1u : 0u;
+                use_sub = np_fit >= SUB_MIN_PREFIXES ? (uniform ? 1u : 3u) : 0u;  // (bit 1: tables per prefix -- long codes are in constant use: strip_span resolves them)
 #if defined(PZG_STATS) && defined(PZG_STATS_NOSUB) && !PZG_DEVICE_PASS
                 use_sub = 0u;  // (lab statistics: how many tokens need the second level at all)
 #endif
@@ -1126,13 +1135,16 @@ struct Decoder {
             }
         }
         if (TREE != TREE_CODELEN && !uniform && np_fit != 0u) {  // the K_SUB entries, in canonical order of the prefixes (offsets = running sum of the table sizes)
-            uint32_t run = 0;
+            uint32_t run = 0, ncut = 0;
 #pragma nounroll
             for (uint32_t q0 = 0; q0 < np_fit; q0 += PZG_WAVE) {
                 const uint32_t q = q0 + lane, c_p = covered_p + q;
                 const uint32_t idx = bitrev32(c_p) >> (32u - P);
                 const uint32_t dq = lut[q < np_fit ? idx : 0u];  // its depth, left there by the counting pass
-                const uint32_t depth = dq < dcap ? dq : dcap;
+                const bool cut = q < np_fit && dq > dcap;        // ... deeper than the cap: the first `dup` of these get one level more
+                const uint64_t cutm = ballot(cut);
+                const uint32_t depth = dq < dcap ? dq : (cut && ncut + mbcnt(cutm) < dup ? dcap + 1u : dcap);
+                ncut += popc64(cutm);
                 const uint32_t size = q < np_fit ? 1u << depth : 0u;
                 const uint32_t incl = wave_iscan_add(size);
                 if (q < np_fit) lut[idx] = mk_stop(depth, K_SUB, sub0 + run + incl - size) | ENT_SUB;
@@ -2371,9 +2383,12 @@ struct Decoder {
         for (uint32_t g = 0; g < 4u; ++g) q[g] = PZG_LV(o.LA[g], k);
     }
     // ... of phase B, for the lanes of `dirty` that have not reached the end of their strip
-    template <bool FX>
+    // INJ (strip_span, codes whose long symbols are in constant use): a step of the lanes of `dirty` alone -- lanes that stood at a token
+    // the tables do not resolve --, each with the token (TBX bits, TKX) that decode_long() found there
+    template <bool FX, bool INJ = false>
     PZG_FN bool strip_step_b(const uint32_t *sp, uint32_t maxdw, bool lsub, bool dsub, uint64_t dirty, StripReader &rd, SeqOut &o,
-                             LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM)
+                             LaneVec<uint32_t> &P, const LaneVec<uint32_t> &LIM, const LaneVec<uint32_t> *TBX = nullptr,
+                             const LaneVec<uint32_t> *TKX = nullptr)
     {
         LaneVec<bool> ACT;
         PZG_LANES_BEGIN(k)
@@ -2381,11 +2396,17 @@ struct Decoder {
             PZG_LV(ACT, k) = lane_bit(dirty, k) & (PZG_LV(o.STF, k) == 0u) & (PZG_LV(P, k) < PZG_LV(LIM, k)) & (PZG_LV(o.NLB, k) < STRIP_TMAX);
         PZG_LANES_END
         if (lanes_ballot(ACT) == 0ull) return false;
-        PZG_MARK("sb.begin");
+        if (!INJ) PZG_MARK("sb.begin");
         PZG_LANES_BEGIN(k)
             strip_top(sp, maxdw, PZG_SR(W0), PZG_SR(W1), PZG_SR(T), PZG_SR(TN), PZG_SR(R), PZG_SR(NX), PZG_SR(PEND));
             uint32_t tb, tk, e2;
-            strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk, e2);
+            if constexpr (INJ) {
+                tb = PZG_LV((*TBX), k);
+                tk = PZG_LV((*TKX), k);
+                e2 = ENT_STOP;  // (no second literal)
+            } else {
+                strip_token<FX>(PZG_SR(W0), PZG_SR(W1), PZG_SR(R), lsub, dsub, tb, tk, e2);
+            }
             const bool act = PZG_LV(ACT, k), stop = tb >= 128u;
             const bool ok = act & !stop;
             PZG_LV(o.STF, k) = (act & stop) ? 1u : PZG_LV(o.STF, k);
@@ -2426,8 +2447,60 @@ struct Decoder {
             if (is_l & ((nlb & 15u) == 0u)) seq_store_lits(o, k, reg_lit(k) + nlb - 16u);
             if (emit & ((nr & (SEQ_G - 1u)) == 0u)) seq_store_records(o, k, reg_rec(k) + nr - SEQ_G);
         PZG_LANES_END
-        PZG_MARK("sb.end");
+        if (!INJ) PZG_MARK("sb.end");
         PZG_STAT(17, 1);  // steps of phase B
+        return true;
+    }
+    // the 64 stream bits at lane k1's position (a lane that has not moved since its last strip_top: R < 64)
+    PZG_FN static uint64_t strip_peek64(const StripReader &rd, uint32_t k1)
+    {
+        const uint32_t r = lane_get(rd.R, k1);
+        const uint64_t w0 = lane_get64(rd.W0, k1), w1 = lane_get64(rd.W1, k1);
+        return r == 0u ? w0 : (w0 >> r) | (w1 << (64u - r));
+    }
+    // The token at the head of the 64 stream bits w, if it is one that only decode_long() resolves (a literal, or a match whose length or
+    // distance code is long); false: anything else -- the lane stays stopped and the span ends there as before.  Wave-uniform, as
+    // token_step_checked() is; nothing is checked against the stream's end here: a lane's position is verified like every other.
+    PZG_FN bool strip_resolve(uint64_t w, uint32_t &tb, uint32_t &tk)
+    {
+        uint32_t bits = (uint32_t)w;
+        bool lng = false;
+        uint32_t e = uni(L.lit_lut[bits & ((1u << LIT_BITS) - 1u)]);
+        uint32_t kind = ent_kind_lit(e);
+        if (kind == K_SUB) {
+            e = uni(L.sub[ent_sub_index(e) + ((bits >> LIT_BITS) & ((1u << ent_n(e)) - 1u))]);
+            kind = ent_kind_lit(e);
+        }
+        if (kind == K_LONG) {
+            e = decode_long<TREE_LITLEN>(bits, &L.lit_meta, L.lens, lit_n, lit_e15);
+            kind = ent_kind_lit(e);
+            lng = true;
+        }
+        if (kind == K_LIT) {
+            tb = ent_n(e);
+            tk = e;
+            return lng;
+        }
+        if (kind != K_BASE) return false;
+        const uint32_t n = ent_base_n(e), tot = ent_base_tot(e);
+        const uint32_t len = ent_len_base(e) + ((bits >> n) & ((1u << (tot - n)) - 1u));
+        bits = (uint32_t)(w >> tot);  // (tot <= 20: 44 bits are left, a distance takes 28 at the most)
+        uint32_t d = uni(L.dist_lut[bits & ((1u << DIST_BITS) - 1u)]);
+        uint32_t dk = ent_kind_dist(d);
+        if (dk == K_SUB) {
+            d = uni(L.sub[ent_sub_index(d) + ((bits >> DIST_BITS) & ((1u << ent_n(d)) - 1u))]);
+            dk = ent_kind_dist(d);
+        }
+        if (dk == K_LONG) {
+            d = decode_long<TREE_DIST>(bits, &L.dist_meta, L.lens + lit_n, dist_n, dist_e15);
+            dk = ent_kind_dist(d);
+            lng = true;
+        }
+        if (dk != K_BASE || !lng) return false;
+        const uint32_t dn = ent_base_n(d), dtot = ent_base_tot(d);
+        const uint32_t dist = ent_val(d) + ((bits >> dn) & ((1u << (dtot - dn)) - 1u));
+        tb = tot + dtot;
+        tk = TK_MATCH | (len << 16) | dist;
         return true;
     }
     // a lane that ran has reached the end of its strip: the literals it ended in become a last record (no match), and its last,
@@ -2845,8 +2918,47 @@ struct Decoder {
                     }
                 PZG_LANES_END
             }
-            for (uint32_t steps = 0; steps < STRIP_TMAX; ++steps)  // (a token a step at the most: the regions cannot overflow)
-                if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM)) break;
+            if (FX || (use_sub & 2u) == 0u) {
+                for (uint32_t steps = 0; steps < STRIP_TMAX; ++steps)  // (a token a step at the most: the regions cannot overflow)
+                    if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM)) break;
+            } else {
+                // (round 6) A code whose long symbols are in constant use (its tables are laid out per prefix: binary-looking records, 250
+                // literals of 8 to 10 bits) has a token every ~200 that the tables do not hold.  Such a token stopped its lane and ended
+                // the span there -- 120 spans' run-ups per 30 KiB stream, or the block left to the windows (`poor`).  Here the lanes that
+                // stop are looked at after every step: decode_long() finds the token, one step of their own takes it, they go on.
+                uint64_t stay = 0ull;  // lanes that stopped at something else: an end of block, an error, a token past the input
+                for (uint32_t steps = 0; steps < STRIP_TMAX; ++steps) {
+                    if (!strip_step_b<FX>(sp, maxdw, lsub, dsub, dirty, rd, o, P, LIM)) break;
+                    LaneVec<bool> ST1;
+                    PZG_LANES_BEGIN(k)
+                        PZG_LV(ST1, k) = PZG_LV(o.STF, k) == 1u;
+                    PZG_LANES_END
+                    uint64_t m = lanes_ballot(ST1) & dirty & ~stay;
+                    if (__builtin_expect(m == 0ull, 1)) continue;
+                    LaneVec<uint32_t> TBX, TKX;
+                    uint64_t inj = 0ull;
+                    do {
+                        const uint32_t k1 = ctz64(m);
+                        m &= m - 1ull;
+                        uint32_t tb = 0u, tk = 0u;
+                        if (strip_resolve(strip_peek64(rd, k1), tb, tk)) {
+                            PZG_LANES_BEGIN(k)
+                                PZG_LV(TBX, k) = k == k1 ? tb : PZG_LV(TBX, k);
+                                PZG_LV(TKX, k) = k == k1 ? tk : PZG_LV(TKX, k);
+                            PZG_LANES_END
+                            inj |= 1ull << k1;
+                        } else {
+                            stay |= 1ull << k1;
+                        }
+                    } while (m != 0ull);
+                    if (inj == 0ull) continue;
+                    PZG_LANES_BEGIN(k)
+                        PZG_LV(o.STF, k) = lane_bit(inj, k) ? 0u : PZG_LV(o.STF, k);
+                    PZG_LANES_END
+                    strip_step_b<FX, true>(sp, maxdw, lsub, dsub, inj, rd, o, P, LIM, &TBX, &TKX);
+                    ++steps;  // (the lanes of inj have taken a step more than the loop counts)
+                }
+            }
             PZG_LANES_BEGIN(k)
                 if (lane_bit(dirty, k)) {
                     // out of steps in front of the end of its strip: the span ends where the lane stands, as at a stopper

@@ -209,6 +209,16 @@ PZG_FN uint32_t lane_get(const LaneVec<uint32_t> &x, uint32_t l)
 #endif
 }
 
+PZG_FN uint64_t lane_get64(const LaneVec<uint64_t> &x, uint32_t l)
+{
+#if PZG_DEVICE_PASS
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x.v, (int)l) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x.v >> 32), (int)l) << 32);
+#else
+    return x.v[l & 63u];
+#endif
+}
+
 // bit k of a wave-uniform mask, as lane k's predicate: on the device the mask itself is the select/branch condition
 // (inverse ballot), no shift and no compare
 PZG_FN bool lane_bit(uint64_t m, uint32_t k)

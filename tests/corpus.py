@@ -111,6 +111,20 @@ def skewed_bytes(nbytes: int, seed: int) -> bytes:
 _HTML = None
 
 
+def binary_records(nbytes: int, seed: int) -> bytes:
+    """Binary-looking data: 16-byte records -- a little-endian counter, a small enum, two random bytes, constants.  Its literal/length
+    code has ~250 symbols of 8 to 10 bits: more second-level entries than the kernels' pool holds (bench.py's hetero workload, kind 3)."""
+    rng = np.random.default_rng(0xB1A0 + seed)
+    nrec = nbytes // 16
+    rec = np.zeros((nrec, 16), dtype=np.uint8)
+    rec[:, 0:4] = (np.arange(nrec, dtype=np.uint32) * 3 + seed).view(np.uint8).reshape(nrec, 4)
+    rec[:, 4] = rng.integers(0, 4, size=nrec)
+    rec[:, 8:10] = rng.integers(0, 256, size=(nrec, 2))
+    rec[:, 12] = 0xff
+    rec[:, 13] = rng.integers(0, 2, size=nrec) * 0x80
+    return rec.tobytes()
+
+
 def html_slice(nbytes: int, seed: int) -> bytes:
     """A slice of the reference's own RFC html fixtures (tests/golden/ref/rfctest*.gold): ~95 distinct
     symbols, literal/length codes up to 13 bits."""

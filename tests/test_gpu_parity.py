@@ -533,6 +533,27 @@ def test_long_codes_second_level_tables(ctx, oracle):
             assert err.show() == r.message.decode(), (k, err.show(), r.message.decode())
 
 
+def test_binary_records_long_codes_inside_spans(ctx, oracle):
+    """Round 6: 16-byte binary-looking records (corpus.binary_records: ~250 literals of 8 to 10 bits, more second-level entries than
+    the pool holds, a token every ~200 that only decode_long() resolves).  The spans' lanes take those tokens through strip_resolve()
+    instead of stopping; what the depth cap leaves of the pool goes to the first prefixes it cut short.  All three levels, 8-64 KiB,
+    valid and corrupted, launched twice (the second launch meets the waves' profiles of the first): every byte against the oracle."""
+    streams, datas = [], []
+    for seed in range(400):
+        d = corpus.binary_records([8, 16, 30, 64, 33][seed % 5] * 1024, seed)
+        streams.append(zlib.compress(d, [6, 1, 9][seed % 3]))
+        datas.append(d)
+    for launch in range(2):
+        (out_len, status, detail, in_used, adler), outs, _, _ = run_batch(ctx, streams, [len(d) for d in datas])
+        for k in range(len(streams)):
+            assert status[k] == 0 and outs[k] == datas[k], (launch, k, status[k], detail[k])
+            assert int(adler[k]) == zlib.adler32(datas[k]) and int(in_used[k]) == len(streams[k])
+    bad = [corpus.corrupt(streams[k % 400], 7000 + k) for k in range(1200)]
+    caps = [len(datas[k % 400]) + (64 if k % 3 else 0) for k in range(1200)]
+    res, outs, _, _ = run_batch(ctx, bad, caps)
+    _check_against_oracle(oracle, bad, caps, res, outs, [None] * len(bad))
+
+
 def test_cxx_module_mirror_reads_like_the_reference_tests():
     """The C++ host mirror of Codec.Compression.Zlib (pure_zlib_amd/cxx/codec_compression_zlib.hpp) driven by
     tests/cxx/test_mirror.cpp: Test.hs's nine cases, decompressMany, the chunk rule, error values, the incremental decoder."""

@@ -137,6 +137,24 @@ def test_model_long_codes_second_level_tables(model, oracle, rb):
             assert same(ro, oo, rm, om), (seed, c, ro.status, rm.status, ro.message)
 
 
+@pytest.mark.parametrize("rb", [11, 15])
+def test_model_binary_records_long_codes_inside_spans(model, oracle, rb):
+    """Round 6: 16-byte binary-looking records -- ~250 literals of 8 to 10 bits, more second-level entries than the pool holds (what the
+    depth cap leaves of it goes to the first prefixes it cut short), and a token every ~200 that only decode_long() resolves: the
+    spans' lanes take those through strip_resolve() instead of stopping.  Valid streams of all three levels and corrupted ones."""
+    for seed in range(16):
+        d = corpus.binary_records([8, 16, 30, 64][seed % 4] * 1024, seed)
+        z = zlib.compress(d, [6, 1, 9][seed % 3])
+        r, out = model(z, len(d), rb)
+        assert r.status == 0 and out == d and r.adler == zlib.adler32(d) and r.in_used == len(z), seed
+        for k in range(6):
+            zc = corpus.corrupt(z, 16 * seed + k)
+            cap = [len(d), len(d) + 100, len(d) // 2][k % 3]
+            ro, oo = oracle.decompress(zc, cap)
+            rm, om = model(zc, cap, rb)
+            assert same(ro, oo, rm, om), (seed, k, ro.status, rm.status, ro.message)
+
+
 @pytest.mark.parametrize("rb,strips", [(11, True), (15, True), (12, True), (11, False)])
 def test_model_strips(model, oracle, rb, strips, monkeypatch):
     """Round 4: long runs of input are decoded by strips (64 lanes, one piece of the input each, from speculative starts that are
@@ -344,6 +362,23 @@ def test_model_incremental_spans_of_strips(model_lib, oracle, rb):
         assert dec.events == eo, (k, len(z), step, room, ro.status)
         if ro.status == 0:
             assert bytes(dec.total) == oo
+
+
+@pytest.mark.parametrize("rb", [12, 15])
+def test_model_incremental_binary_records(model_lib, oracle, rb):
+    """... and the resumable instance's spans (pieces large enough for them, rooms that cut them): whole event traces."""
+    for seed in range(6):
+        d = corpus.binary_records([16, 30, 64][seed % 3] * 1024, seed)
+        z = zlib.compress(d, [6, 1, 9][seed % 3])
+        for piece, room in ((8192, 1 << 20), (20000, 9 * 1024), (len(z), 40000)):
+            pieces = [z[i:i + piece] for i in range(0, len(z), piece)]
+            eo, ro, oo = oracle.trace(pieces)
+            dec = ModelDecoder(model_lib, room, rb)
+            for pc in pieces:
+                if not dec.feed(pc):
+                    break
+            assert ro.status == 0 and dec.events == eo, (seed, piece, room)
+            assert bytes(dec.total) == oo == d
 
 
 @pytest.mark.parametrize("rb", [12, 15])
