@@ -83,7 +83,7 @@ def test_event_trace_spans_of_strips_and_the_scratch_cap(gpu_ctx, oracle):
     """Round 5: the resumable kernel decodes by strips too (a span inside one call, cut to the call's room, far matches from the
     decoder's history, the reference's chunk count kept per group).  The bench's shape (256 KiB of text in 32 KiB pieces, 192 KiB
     rooms), rooms that cut spans short, writer-made streams (tests/deflate_writer.py), html + literal-heavy data and corrupted
-    variants -- 24 decoders fed in lockstep, one launch per feed -- with the library's scratch unlimited, capped at 32 MiB
+    variants, binary-looking records -- 30 decoders fed in lockstep, one launch per feed -- with the library's scratch unlimited, capped at 32 MiB
     (PZG_OPT_SCRATCH_BYTES: some stream-waves get no slice) and withheld altogether (a 1-byte cap: the windows alone): the same
     event traces and bytes as the oracle every time."""
     import deflate_writer as W
@@ -96,6 +96,10 @@ def test_event_trace_spans_of_strips_and_the_scratch_cap(gpu_ctx, oracle):
         zs += [z, corpus.corrupt(z, seed)]
     z = zlib.compress(corpus.html_slice(60000, 1) + corpus.skewed_bytes(90000, 2), 6)
     zs += [z, corpus.corrupt(z, 5), zlib.compress(corpus.mixed_data(300000, 4), 9), zlib.compress(corpus.zipf_text(100000, 3), 1)]
+    # (round 6: binary-looking records -- long codes in constant use, resolved inside the spans: strip_resolve())
+    for seed in range(3):
+        z = zlib.compress(corpus.binary_records(160 * 1024, seed), [6, 1, 9][seed])
+        zs += [z, corpus.corrupt(z, 40 + seed)]
     n = len(zs)
     try:
         for cap, step, room in ((0, 32768, 192 * 1024), (32 << 20, 32768, 24 * 1024), (1, 20000, 70000), (0, 50000, 9 * 1024)):
