@@ -429,3 +429,32 @@ def exotic_stream(seed):
     data = bytes(out)
     z = bytes([0x78, 0x9c]) + w.bytes() + zlib.adler32(data).to_bytes(4, "big")
     return data, z, note
+
+
+def pool_stream(seed):
+    """(data, zlib stream): dynamic blocks long enough for the kernels' spans whose literal/length code has 150-256 literals of 8 to
+    12 bits in constant use -- codes that need a little less, a little more or much more than the 252 second-level entries the kernels'
+    pool holds (round 6: the depth cap's remainder goes to the first prefixes it cut short; long codes are resolved inside the spans)."""
+    rng = random.Random(0x9001 + seed * 104729)
+    out = bytearray()
+    w = BitWriter()
+    nblocks = 1 + seed % 3
+    for bi in range(nblocks):
+        k = rng.choice([150, 180, 200, 220, 240, 256])
+        syms = rng.sample(range(256), k)
+        # a few frequent symbols (short codes), a broad middle (8-9 bits), a tail two to sixteen times rarer (10-12 bits)
+        hot = rng.randint(0, 6)
+        tail = rng.randint(0, k // 2)
+        pool = []
+        for i, sy in enumerate(syms):
+            wgt = 400 if i < hot else (rng.choice([1, 2, 4]) if i >= k - tail else 16)
+            pool += [sy] * wgt
+        b = Block("dynamic")
+        b.tokens = gen_tokens(rng, out, rng.choice([9000, 20000, 45000]),
+                              dict(alphabet=pool, lens=[3, 3, 4, 4, 5, 6, 8, 12, 30, 100], dists=rng.choice(["near", "any", "far", 16]),
+                                   p_match=rng.choice([0.0, 0.1, 0.3, 0.5])))
+        b.opts = {}
+        write_block(w, b, bi == nblocks - 1, rng, dict(codes="huffman", rle="rle"))
+    d = bytes(out)
+    import zlib
+    return d, bytes([0x78, 0x9c]) + w.bytes() + zlib.adler32(d).to_bytes(4, "big")

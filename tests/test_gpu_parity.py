@@ -554,6 +554,21 @@ def test_binary_records_long_codes_inside_spans(ctx, oracle):
     _check_against_oracle(oracle, bad, caps, res, outs, [None] * len(bad))
 
 
+def test_codes_around_the_second_level_pool(ctx, oracle):
+    """... and writer-made codes of 150-256 literals of 8 to 13 bits (deflate_writer.pool_stream: a little less, a little more and much
+    more than the pool's 252 second-level entries; one to three blocks, every kind of distance), 240 valid streams and 720 corrupted ones
+    in one launch, against the oracle."""
+    import deflate_writer as W
+    streams, caps, datas = [], [], []
+    for seed in range(240):
+        d, z = W.pool_stream(seed)
+        streams.append(z); caps.append(len(d)); datas.append(d)
+        for k in range(3):
+            streams.append(corpus.corrupt(z, 8 * seed + k)); caps.append([len(d), len(d) + 100, len(d) // 2][k]); datas.append(None)
+    res, outs, _, _ = run_batch(ctx, streams, caps)
+    _check_against_oracle(oracle, streams, caps, res, outs, datas)
+
+
 def test_cxx_module_mirror_reads_like_the_reference_tests():
     """The C++ host mirror of Codec.Compression.Zlib (pure_zlib_amd/cxx/codec_compression_zlib.hpp) driven by
     tests/cxx/test_mirror.cpp: Test.hs's nine cases, decompressMany, the chunk rule, error values, the incremental decoder."""

@@ -155,6 +155,26 @@ def test_model_binary_records_long_codes_inside_spans(model, oracle, rb):
             assert same(ro, oo, rm, om), (seed, k, ro.status, rm.status, ro.message)
 
 
+@pytest.mark.parametrize("rb", [11, 15])
+def test_model_codes_around_the_second_level_pool(model, oracle, rb):
+    """Writer-made blocks (deflate_writer.pool_stream) whose literal/length codes have 150-256 symbols of 8 to 13 bits in constant
+    use: a little less, a little more and much more than the pool's 252 entries -- every depth cap, with and without a remainder for the
+    prefixes it cut short (build_table: dup), long codes of literals, lengths and distances met by the spans' lanes (strip_resolve).
+    Valid and corrupted, against the oracle."""
+    import deflate_writer as W
+    for seed in range(96):
+        d, z = W.pool_stream(seed)
+        ro, oo = oracle.decompress(z, len(d))
+        rm, om = model(z, len(d), rb)
+        assert ro.status == 0 and oo == d and same(ro, oo, rm, om), (seed, ro.status, rm.status)
+        for k in range(4):
+            zc = corpus.corrupt(z, 8 * seed + k)
+            cap = [len(d), len(d) + 100, len(d) // 2][k % 3]
+            ro, oo = oracle.decompress(zc, cap)
+            rm, om = model(zc, cap, rb)
+            assert same(ro, oo, rm, om), (seed, k, ro.status, rm.status, ro.message)
+
+
 @pytest.mark.parametrize("rb,strips", [(11, True), (15, True), (12, True), (11, False)])
 def test_model_strips(model, oracle, rb, strips, monkeypatch):
     """Round 4: long runs of input are decoded by strips (64 lanes, one piece of the input each, from speculative starts that are
