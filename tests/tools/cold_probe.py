@@ -22,6 +22,6 @@ if mode == "full_small_first":   # as many streams as the chip holds waves, tiny
     s2 = DeviceBatch(tv[:64], zv[:64], pk)
     s2.run(ctx, 11); print("6656 streams", round(ctx.last_kernel_ms(), 3))
 ms = []
-for i in range(4):
+for i in range(int(os.environ.get("COLD_N", "4"))):
     vb.run(ctx, 11); ms.append(round(ctx.last_kernel_ms(), 3))
 print(mode, ms)
