@@ -133,8 +133,8 @@ def build_pool(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=6)  # (the rate settles over a process' first five or six launches: profiles/r06_strips.txt 11)
     ap.add_argument("--workload", default="l6_32k", choices=["l6_32k", "fixed_4k", "mixed", "skewed_bytes", "html", "runs", "fixed_bin", "hetero"])
     ap.add_argument("--streams", type=int, default=65536, help="streams per GPU")
     ap.add_argument("--blob-bytes", type=int, default=32768)
