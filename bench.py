@@ -440,6 +440,9 @@ def main():
         def variant(name, what, texts_v, zs_v, count, seed, profile=None):
             pick_v = np.random.default_rng(seed).integers(0, len(zs_v), size=count)
             vb = DeviceBatch(texts_v, zs_v, pick_v, dev=local_rank)
+            # (another kind of batch begins: the context looks for streams for the bundles again instead of waiting out the launches it
+            # goes without looking after the headline's sixteen -- pzg.h PZG_OPT_BUNDLES; what an application that knows its data does)
+            ctx.set_bundles(args.bundles if args.bundles >= 0 else 1)
             if profile is not None:
                 ctx.set_profile(profile)
             ok_v = True

@@ -189,7 +189,8 @@ PZG_API int  pzg_sync(pzg_ctx *ctx);
  *   stream; every other stream, and every stream that is not plain (another block type, any error, a stream or capacity of a MiB or
  *   more), is decoded by the ordinary one-stream-per-wavefront kernel as before; a launch in which no stream turned out to be one for
  *   the bundles lets the next 2, 6, 14 ... 64 launches of the context go without looking (the look costs such a launch ~1 %).
- *   2 -- launches of any size, always looking.  0 -- off.  Results never depend on it; it needs no scratch memory. */
+ *   2 -- launches of any size, always looking.  0 -- off.  Results never depend on it; it needs no scratch memory.
+ *   Setting the option (to the value it already has, too) ends the launches a context is going without looking. */
 #define PZG_OPT_BUNDLES 4
 /* PZG_OPT_PROFILE (0.5): 1 (default) -- a stream-wave of a PZG_DEVICE_PTRS launch remembers where the tokens of the last stream it
  *   decoded lay and cuts the next stream's input into pieces of equal WORK there (checked against the stream itself before it is

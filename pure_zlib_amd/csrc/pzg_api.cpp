@@ -1096,6 +1096,13 @@ int pzg_set_option(pzg_ctx *ctx, int option, int64_t value)
     }
     if (option == PZG_OPT_BUNDLES && value >= 0 && value <= 2) {
         ctx->bundles.store((int)value);
+        // (setting it -- to the value it has, too -- makes the next launch look again: a caller that knows its next batches are of
+        // another kind need not wait out the launches a context goes without looking after batches that had nothing for the bundles)
+        for (auto &s : ctx->shards) {
+            std::lock_guard<std::mutex> g(s->mu);
+            s->bundle_skip = 0u;
+            s->bundle_backoff = 0u;
+        }
         return PZG_RC_OK;
     }
     if (option == PZG_OPT_HOST_THREADS && value >= 1 && value <= 256) {  // (not while host-pointer calls are running)

@@ -149,3 +149,29 @@ def test_config3_share_at_the_default_setting(gpu_ctx, oracle):
             b.check_sample_vs_oracle(oracle, 64)
     finally:
         gpu_ctx.set_bundles(1)
+
+
+def test_setting_the_option_makes_the_next_launch_look_again(gpu_ctx):
+    """A context whose launches had nothing for the bundles goes 2, 6, 14 ... 64 launches without looking (pzg.h PZG_OPT_BUNDLES); setting
+    the option -- to the value it has -- ends that.  Four launches of dynamic-code streams, then streams of the fixed code: decoded by
+    the ordinary kernel (the context is not looking), and after set_bundles(1) by the bundles -- told apart by the kernels' time (config
+    3's streams: 1.4 ms against 1.1), every byte checked both ways."""
+    texts = [corpus.zipf_text(4096, s) for s in range(256)]
+    dyn = DeviceBatch(texts, [zlib.compress(t, 6) for t in texts], np.random.default_rng(1).integers(0, 256, size=40000))
+    fx = DeviceBatch(texts, [fixed(t) for t in texts], np.random.default_rng(2).integers(0, 256, size=65536))
+    try:
+        gpu_ctx.set_bundles(1)
+        for _ in range(4):
+            dyn.check_all(*dyn.run(gpu_ctx, 11))
+        slow = []
+        for _ in range(2):
+            fx.check_all(*fx.run(gpu_ctx, 11))
+            slow.append(gpu_ctx.last_kernel_ms())
+        gpu_ctx.set_bundles(1)
+        fast = []
+        for _ in range(3):
+            fx.check_all(*fx.run(gpu_ctx, 11))
+            fast.append(gpu_ctx.last_kernel_ms())
+        assert min(fast[1:]) < 0.92 * min(slow), (slow, fast)
+    finally:
+        gpu_ctx.set_bundles(1)
