@@ -2137,9 +2137,13 @@ struct Decoder {
     static constexpr uint32_t STRIP_BACK_MIN = PZG_STRIP_BACK_MIN < PZG_STRIP_BACK ? PZG_STRIP_BACK_MIN : PZG_STRIP_BACK;
     static constexpr uint32_t STRIP_BACK_DOWN = 32u, STRIP_BACK_UP = 256u;
 #ifndef PZG_STRIP_CMIN
-#define PZG_STRIP_CMIN 256
+#define PZG_STRIP_CMIN 64  // (256 until round 6: set when a span's tokens were emitted by segments; with the groups, strips of a few tokens pay)
 #endif
     static constexpr uint32_t STRIP_CMIN = PZG_STRIP_CMIN;      // shorter strips are not worth a span
+#ifndef PZG_STRIP_BACK_PER_C
+#define PZG_STRIP_BACK_PER_C 2
+#endif
+    static constexpr uint32_t STRIP_BACK_PER_C = PZG_STRIP_BACK_PER_C;  // the run-up of short strips, in strips
 #ifndef PZG_STRIP_ROUNDS
 #define PZG_STRIP_ROUNDS 6
 #endif
@@ -2838,6 +2842,14 @@ struct Decoder {
         // phase A: the run-up
         uint32_t back = uni(L.strip_back);
         if (back < STRIP_BACK_MIN || back > STRIP_BACK) back = STRIP_BACK;
+        // (round 6) short strips: a run-up many times a strip's length is most of a small stream's work, and a guess that fails costs
+        // only a second pass over strips of a few tokens -- the run-up is STRIP_BACK_PER_C strips at the most (not below the shortest one
+        // the controller uses; what the wave has learned on long strips is left alone).  Measured with the strips' shortest length at 64
+        // bits instead of 256 (GiB/s, 1 M x 2 KiB / 512 K x 4 KiB level-6 streams; before: 107.2 / 135.5 -- the windows' business until
+        // then): no cap 126.8 / 186.0, 2 strips 129.6 / 192.1, 3 strips 133.5 / 183.8, 4 strips 130.7 / 173.4, 6 strips 120.1 / 185.6.
+        const uint32_t back_cap = STRIP_BACK_PER_C * C > STRIP_BACK_MIN ? STRIP_BACK_PER_C * C : STRIP_BACK_MIN;
+        const bool back_cut = back > back_cap;
+        if (back_cut) back = back_cap;
         StripReader rd;
         LaneVec<uint32_t> P, S, LIM;
         // (short strips -- a 4 KiB stream's hold ~30 tokens -- differ by chance more than by position: no profile for them)
@@ -2989,7 +3001,7 @@ struct Decoder {
         {   // what the next span's run-up learns from this one: the first round's guesses all held, or not
             const uint32_t nb = !(repaired || dirty != 0ull) ? (back >= STRIP_BACK_MIN + STRIP_BACK_DOWN ? back - STRIP_BACK_DOWN : STRIP_BACK_MIN)
                                             : (back + STRIP_BACK_UP <= STRIP_BACK ? back + STRIP_BACK_UP : STRIP_BACK);
-            if (lane_id() == 0u || PZG_WAVE == 1u) L.strip_back = nb;
+            if (!back_cut && (lane_id() == 0u || PZG_WAVE == 1u)) L.strip_back = nb;
         }
         if (dirty != 0ull) {  // still a lane that started in the wrong place: the span ends in front of it
             last = ctz64(dirty) - 1u;
