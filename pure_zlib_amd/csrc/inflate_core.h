@@ -2848,7 +2848,7 @@ struct Decoder {
         // bits instead of 256 (GiB/s, 1 M x 2 KiB / 512 K x 4 KiB level-6 streams; before: 107.2 / 135.5 -- the windows' business until
         // then): no cap 126.8 / 186.0, 2 strips 129.6 / 192.1, 3 strips 133.5 / 183.8, 4 strips 130.7 / 173.4, 6 strips 120.1 / 185.6.
         const uint32_t back_cap = STRIP_BACK_PER_C * C > STRIP_BACK_MIN ? STRIP_BACK_PER_C * C : STRIP_BACK_MIN;
-        const bool back_cut = back > back_cap;
+        const bool back_cut = C < STRIP_BACK_MIN && back > back_cap;  // (strips of 256 bits or more keep what the wave has learned: 8 KiB streams 238 -> 245)
         if (back_cut) back = back_cap;
         StripReader rd;
         LaneVec<uint32_t> P, S, LIM;

@@ -10,6 +10,7 @@ run() { # lib args...
 for lib in ${LIBS:-product}; do
   run $lib --workload l6_32k --streams 1048576 --blob-bytes 2048 --pool 4096
   run $lib --workload l6_32k --streams 524288 --blob-bytes 4096 --pool 4096
+  run $lib --workload l6_32k --streams 262144 --blob-bytes 8192 --pool 4096
   run $lib --workload l6_32k
   run $lib --workload fixed_4k --bundles 0
 done
