@@ -18,5 +18,7 @@ run --workload mixed --streams 131072
 run --workload l6_32k --gzip
 run --workload l6_32k --streams 32768 --blob-bytes 65536
 run --workload l6_32k --streams 1048576 --blob-bytes 2048 --pool 4096
+run --workload l6_32k --streams 524288 --blob-bytes 4096 --pool 4096
+run --workload l6_32k --streams 262144 --blob-bytes 8192 --pool 4096
 [ -n "$SWEEP_RINGS" ] && for rb in 12 13 14 15; do run --ring-bits $rb; done
 true
