@@ -198,7 +198,7 @@ def splitmix64_torch(first, count, dev):
 
 
 def strip_case(seed: int):
-    """(data, stream) long enough for the kernels' strips (spans of 64 x 256 input bits or more): text, html, literal-heavy
+    """(data, stream) long enough for the kernels' strips (spans of 64 x 256 input bits or more: the shortest span until round 6; 64 x 64 bits since): text, html, literal-heavy
     bytes, four-symbol data (two-bit codes: the shortest strips), pieces of all of them in one stream; one block or many
     (seeded flush points, fixed / Huffman-only / RLE strategies, stored blocks at level 0)."""
     rng = random.Random(90000 + seed)
