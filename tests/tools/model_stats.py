@@ -1,6 +1,6 @@
 """Lab tool: event counts of the token loop (windows, segments and why they end, bytes per segment, checked steps) from the
 HOST model of the kernel source built with -DPZG_STATS, over a workload of bench.py.  Usage:
-    python tests/tools/model_stats.py [l6_32k|fixed_4k|html|skewed_bytes] [count]"""
+    python tests/tools/model_stats.py [l6_32k|l6_2k|l6_4k|l6_8k|fixed_4k|html|skewed_bytes|hetero_bin] [count]"""
 import ctypes as C
 import os
 import subprocess
@@ -54,13 +54,17 @@ def main():
             sys.path.insert(0, ROOT)
             import bench
             t, z = bench.hetero_blob(4 * seed + 3)
+        elif wl in ("l6_2k", "l6_4k", "l6_8k"):
+            nb = {"l6_2k": 2048, "l6_4k": 4096, "l6_8k": 8192}[wl]
+            t = corpus.zipf_text(nb, seed)
+            z = zlib.compress(t, 6)
         elif wl == "skewed_bytes":
             t = corpus.skewed_bytes(32768, seed)
             z = zlib.compress(t, 6)
         else:
             t = corpus.zipf_text(32768, seed)
             z = zlib.compress(t, 6)
-        out = C.create_string_buffer(len(t) + 16)
+        out = C.create_string_buffer(len(t) + 16)  # (l6_2k / l6_4k / l6_8k: small level-6 text streams)
         r = R()
         assert M.pzm_decompress(z, len(z), out, len(t), 11, C.byref(r)) == 0 and r.status == 0 and out.raw[:len(t)] == t
         tot_out += len(t)
